@@ -1,0 +1,214 @@
+/*
+ * yolov4_amd.h -- C ABI of libyolov4_amd.so: the MI355X (gfx950) hot path of YOLOv4.
+ *
+ * The reference (zjykzj/YOLOv4) has no FFI of its own: its hot path is a set of Python
+ * nn.Module classes whose arithmetic runs inside PyTorch ATen.  Each entry
+ * point below therefore cites the reference Python interface (file:line under /root/reference)
+ * whose arithmetic it replaces; the Python classes of the same names in yolov4_amd/ bind these
+ * symbols with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - activations are NHWC fp32 with an explicit pixel pitch `ld*` (elements between two
+ *     consecutive pixels, >= channel count), so a channel slice of a wider buffer is a
+ *     valid operand (zero-copy concat / split);
+ *   - conv filters are KRSC fp32: w[Cout][k][k][Cin], i.e. the reference's
+ *     nn.Conv2d.weight [Cout,Cin,k,k] held in torch.channels_last memory format;
+ *   - `stream` is a hipStream_t passed as void*; work is only enqueued, no call synchronises,
+ *     allocates or frees (workspaces are caller-provided; *_workspace() return their size);
+ *   - return value: Y4_OK or a Y4_ERR_* code; y4_strerror() names it.  Shapes are validated on
+ *     the host before any launch.
+ */
+#ifndef YOLOV4_AMD_H
+#define YOLOV4_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Y4_OK 0
+#define Y4_ERR_SHAPE 1      /* unsupported / inconsistent shape or pitch            */
+#define Y4_ERR_NULL 2       /* required pointer is NULL                             */
+#define Y4_ERR_LAUNCH 3     /* hipLaunch / hipMemsetAsync reported an error         */
+#define Y4_ERR_WORKSPACE 4  /* workspace too small                                  */
+#define Y4_ERR_NODEVICE 5   /* no gfx950 device visible                             */
+
+/* activation ids: darknet/darknet.py:41-51 ('relu' | 'leaky_relu' (0.1) | 'mish' | 'linear') */
+#define Y4_ACT_LINEAR 0
+#define Y4_ACT_LEAKY 1
+#define Y4_ACT_MISH 2
+#define Y4_ACT_RELU 3
+
+const char* y4_strerror(int code);
+int y4_version(void);
+/* number of visible HIP devices whose arch is gfx950 (0 if none) */
+int y4_device_count(void);
+
+/* ---------------------------------------------------------------- convolution
+ * Replaces nn.Conv2d inside ConvBNAct.forward, darknet/darknet.py:31-36,53-54
+ * (k in {1,3}, stride in {1,2}, pad=(k-1)//2, dilation 1, groups 1).
+ *
+ * y[b,ho,wo,n] = act( (sum_{r,q,c} x[b,ho*s-pad+r,wo*s-pad+q,c] * w[n,r,q,c]) * scale[n] + shift[n] )
+ *                + residual[b,ho,wo,n]
+ * scale/shift/residual may be NULL (identity / 0).  Eval-mode BatchNorm folds into
+ * scale/shift (darknet.py:55), the bias of the 3 head convs into shift (yolov4.py:237,243,249),
+ * ResBlock's skip into residual (darknet.py:76-80).  Implicit GEMM on
+ * v_mfma_f32_32x32x2_f32 (exact fp32).  Requires Cin % 32 == 0, or Cin == 3 (stem,
+ * yolov4.py:30: direct kernel, x given with arbitrary element strides).
+ */
+int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
+                      int B, int H, int W, int Cin, int Cout, int k, int stride,
+                      const float* scale, const float* shift, int act,
+                      const float* residual, int ldr, void* stream);
+
+/* Stem conv (Cin = 3): x addressed as x[b*sxb + c*sxc + h*sxh + w*sxw] so both the NCHW
+ * tensor the reference feeds (yolo/engine/build.py:60) and NHWC work without a copy. */
+int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
+                           const float* w, float* y, int ldy, int B, int H, int W, int Cout,
+                           const float* scale, const float* shift, int act, void* stream);
+
+/* dgrad: dx[B,H,W,Cin] = conv_transpose(dy[B,Ho,Wo,Cout], w) -- autograd of nn.Conv2d wrt input.
+ * workspace: y4_conv2d_dgrad_workspace() bytes (holds the [Cin][k][k][Cout4] transposed filter). */
+size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k);
+int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                        int B, int H, int W, int Cin, int Cout, int k, int stride,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* wgrad: dw[Cout][k][k][Cin] = sum_{b,ho,wo} dy (x) x -- autograd of nn.Conv2d wrt weight.
+ * Split-K over pixels into fp32 slabs in `workspace`, reduced in a fixed order (deterministic). */
+size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride);
+int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                        int B, int H, int W, int Cin, int Cout, int k, int stride,
+                        void* workspace, size_t workspace_bytes, void* stream);
+size_t y4_conv2d_stem_wgrad_workspace(int B, int H, int W, int Cout);
+int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
+                             const float* dy, int lddy, float* dw, int B, int H, int W, int Cout,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm + activation
+ * Replaces nn.BatchNorm2d (training mode: batch statistics, eps 1e-5, momentum 0.1, biased
+ * variance for normalisation, unbiased for running_var) + the activation,
+ * darknet/darknet.py:37-51,55-56.  M = B*H*W pixels, C channels.
+ *
+ * y4_bn_stats_f32: mean[c], invstd[c] = 1/sqrt(var_biased+eps); running stats updated in place
+ *   (running = (1-m)*running + m*batch; running_var uses var*M/(M-1)); *num_batches_tracked += 1.
+ *   running_mean/running_var/num_batches_tracked may be NULL.  workspace: 2*C doubles.
+ */
+size_t y4_bn_workspace(int C);
+int y4_bn_stats_f32(const float* y, int ldy, long long M, int C, float* mean, float* invstd,
+                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+/* z = act(gamma*(y-mean)*invstd + beta) + residual   (residual may be NULL) */
+int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int act,
+                      const float* residual, int ldr, float* z, int ldz,
+                      long long M, int C, void* stream);
+/* Backward of the two ops above wrt y, gamma, beta given dz (grad wrt z; the residual branch
+ * receives dz itself).  dy may alias dz.  workspace: 2*C doubles. */
+int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      int act, float* dy, int lddy, float* dgamma, float* dbeta,
+                      long long M, int C, void* workspace, size_t workspace_bytes, void* stream);
+/* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249). workspace: C doubles */
+int y4_bias_grad_f32(const float* dy, int lddy, long long M, int C, float* dbias,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* eval-mode fold (darknet.py:55 in eval): scale = gamma/sqrt(running_var+eps),
+ * shift = beta - running_mean*scale */
+int y4_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, float eps, float* scale, float* shift, int C, void* stream);
+
+/* ---------------------------------------------------------------- pointwise glue
+ * torch.cat along channels (darknet.py:110,135; yolov4.py:71,139,146,181,186): copy src[M,C]
+ * into dst[:, c_off:c_off+C]. */
+int y4_copy_channels_f32(const float* src, int lds, float* dst, int ldd, long long M, int C, void* stream);
+/* out[M,C] = a[M,C] + b[M,C] (gradient fan-in at forks: residual skip, CSP split, FPN/PAN taps);
+ * out may alias a or b. */
+int y4_add_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
+               long long M, int C, void* stream);
+/* nn.MaxPool2d(ksize, stride 1, pad ksize//2), yolov4.py:60-62,68-70.  idx (int8, per output
+ * element: window offset dy*ksize+dx of the first maximum) may be NULL in inference. */
+int y4_maxpool_s1_fwd_f32(const float* x, int ldx, float* y, int ldy, signed char* idx,
+                          int B, int H, int W, int C, int ksize, void* stream);
+int y4_maxpool_s1_bwd_f32(const float* dy, int lddy, const signed char* idx, float* dx, int lddx,
+                          int accumulate, int B, int H, int W, int C, int ksize, void* stream);
+/* nearest x2 upsample, yolov4.py:77-90, and its adjoint (2x2 block sum). */
+int y4_upsample2x_fwd_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream);
+int y4_upsample2x_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int B, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------- YOLO head decode
+ * Replaces YOLOLayer.forward, yolo/model/yololayer.py:88-166.  logits: head conv output
+ * NHWC [B,F,F,>=A*(5+C)] pitch ldl; anchors_wh: A pairs (w,h) in grid units (host array).
+ * train: output [B,A,F,F,5+C] (sigmoid on ch 0,1,4..; raw 2,3) and pred [B,A,F,F,4] (grid units).
+ * eval : out[b, box_off + a*F*F + j*F + i, :] of an [B,n_total,5+C] buffer, boxes x stride. */
+int y4_yolo_decode_train_f32(const float* logits, int ldl, float* output, float* pred,
+                             int B, int F, int A, int n_classes, const float* anchors_wh_host, void* stream);
+int y4_yolo_decode_eval_f32(const float* logits, int ldl, float* out, long long n_total, long long box_off,
+                            int B, int F, int A, int n_classes, const float* anchors_wh_host,
+                            float stride, void* stream);
+/* d(logits) (NHWC, pitch ldl, pad channels zeroed) from d(output) and d(pred) (either NULL). */
+int y4_yolo_decode_bwd_f32(const float* logits, int ldl, const float* g_output, const float* g_pred,
+                           float* g_logits, int B, int F, int A, int n_classes,
+                           const float* anchors_wh_host, void* stream);
+
+/* ---------------------------------------------------------------- detection loss
+ * Replaces YOLOLoss.build_target + YOLOLoss.forward for one layer,
+ * yolo/model/yololoss.py:118-371,385-432.  labels: [B,K,5] fp32 rows (xc,yc,w,h,cls) in input
+ * pixels.  all_anchors_host: 9 (w,h) pairs in grid units of this layer; anch_mask_host: the A
+ * indices of this layer.  Outputs (all device):
+ *   obj_mask [B,A,F,F] fp32, pos_index [B,A,F,F] int32 (-1 or index into pos_rec),
+ *   pos_rec [B,K,8+ceil(C/32)] (x,y,w,h targets, scale, cell, class bitmask), npos [B],
+ *   loss_parts[4] doubles (xy, wh, obj, cls), deterministic two-stage reduction.
+ * workspace: y4_yolo_loss_workspace() bytes.
+ */
+size_t y4_yolo_loss_workspace(int B, int F, int A, int K, int n_classes);
+int y4_yolo_loss_fwd_f32(const float* output, const float* pred, const float* labels, int K,
+                         int B, int F, int A, int n_classes, float stride, float ignore_thresh,
+                         const float* all_anchors_host, int n_all_anchors, const int* anch_mask_host,
+                         float* obj_mask, double* loss_parts,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* grad wrt `output` (dense [B,A,F,F,5+C]) scaled by *gscale (DEVICE scalar: the upstream grad of
+ * the loss, so no host sync is needed); uses the workspace filled by fwd.  output_is_masked = 1
+ * when y4_yolo_loss_mask_output_f32 has already been applied to `output` (the reference's
+ * in-place side effect): the w/h channels then hold o*scale. */
+int y4_yolo_loss_bwd_f32(const float* output, int output_is_masked, const float* obj_mask,
+                         const float* gscale, float* g_output,
+                         int B, int F, int A, int K, int n_classes,
+                         const void* workspace, size_t workspace_bytes, void* stream);
+/* the reference's in-place side effect on outputs[*]['output'] (yololoss.py:402-407) */
+int y4_yolo_loss_mask_output_f32(float* output, const float* obj_mask, int B, int F, int A, int K,
+                                 int n_classes, const void* workspace, size_t workspace_bytes, void* stream);
+/* dense views of the sparse targets for API parity / tests (yololoss.py:173-187 tensors) */
+int y4_yolo_loss_dense_targets_f32(float* target, float* tgt_mask, float* tgt_scale,
+                                   int B, int F, int A, int K, int n_classes,
+                                   const void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- post-processing
+ * Replaces postprocess + nms, yolo/util/utils.py:32-89,92-223.
+ * Stage 1: xywh->xyxy in place on prediction [B,N,5+C] and count candidates
+ *          (obj*cls >= conf) per (image, class) into counts[B*C] (int32, zeroed inside).
+ * Stage 2: (host gives exclusive offsets of counts) fill candidate keys, sort inside each
+ *          (image, class) segment by (score desc, box index asc), greedy NMS (IoU >= thr
+ *          suppresses), write kept rows [x1,y1,x2,y2,obj,cls_conf,cls] compacted per segment
+ *          and kept[B*C] counts.
+ */
+int y4_post_count_f32(float* prediction, int B, long long N, int n_classes, float conf_thre,
+                      int convert_xyxy, int* counts, void* stream);
+size_t y4_post_nms_workspace(long long total_candidates, int n_segments);
+int y4_post_nms_f32(const float* prediction, int B, long long N, int n_classes, float conf_thre,
+                    float nms_thre, const int* seg_offsets /* [B*C+1] device */, long long total_candidates,
+                    float* det_rows /* [total,7] */, int* kept /* [B*C] */,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* plain greedy NMS on one list (nms(), utils.py:32): boxes [R,4] xyxy, order given by
+ * score desc / index asc; writes keep flags in sorted order and the sorted index list. */
+size_t y4_nms_workspace(long long R);
+int y4_nms_f32(const float* boxes, const float* scores /* may be NULL */, long long R, float thresh,
+               int limit, int* keep_idx /* [R] */, int* n_keep /* [1] */,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOV4_AMD_H */

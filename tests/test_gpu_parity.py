@@ -1,0 +1,421 @@
+# -*- coding: utf-8 -*-
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same
+seeded inputs and against the golden fixtures the reference produced.
+
+Tolerances (north_star): bit-exact for anchor indices, masks and NMS survivor
+sets; abs 1e-4 on per-cell fp32 tensors (scaled by the tensor's magnitude for
+unbounded ones: boxes in pixels, conv outputs, gradients); rel 1e-4 on the loss
+scalar (an un-normalised fp32 sum).
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import recipe
+from oracle import head as H
+from oracle import network as NW
+
+pytestmark = pytest.mark.gpu
+
+CFG = recipe.MODEL_CFG
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    import yolov4_amd
+    assert yolov4_amd.lib().y4_device_count() >= 1, 'no gfx950 device visible to libyolov4_amd.so'
+    return torch.device('cuda:0')
+
+
+def close(a, b, atol=1e-4, rtol=1e-4, scale=True):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    s = max(1.0, float(np.abs(b).max())) if scale else 1.0
+    np.testing.assert_allclose(a, b, atol=atol * s, rtol=rtol)
+
+
+def cl(t, dev):
+    return t.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------ raw conv kernels
+CONV_CASES = [
+    # B, Cin, Cout, k, s, H, W
+    (2, 32, 64, 3, 1, 9, 9),
+    (3, 64, 128, 3, 2, 13, 13),       # odd size, stride 2
+    (2, 128, 128, 1, 1, 12, 12),
+    (1, 256, 255, 3, 1, 10, 10),      # head conv: Cout = 255 (masked column)
+    (2, 64, 32, 1, 1, 20, 20),        # Cout = 32 tile
+    (2, 32, 64, 3, 2, 16, 16),
+    (5, 512, 256, 1, 1, 7, 7),        # M = 245 (not a multiple of the 128-row tile)
+    (2, 2048, 512, 1, 1, 5, 5),       # SPP conv2 depth
+    (1, 32, 32, 3, 1, 40, 40),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dev, case):
+    from yolov4_amd import ops
+    B, Cin, Cout, k, s, Hh, Ww = case
+    x = recipe.randn((B, Cin, Hh, Ww), 1)
+    w = recipe.randn((Cout, Cin, k, k), 2, 1.0 / np.sqrt(Cin * k * k))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, s, (k - 1) // 2)
+    gy = recipe.randn(tuple(yr.shape), 3)
+    yr.backward(gy)
+    y = ops.conv_fwd_raw(cl(x, dev), cl(w, dev), k, s)
+    close(y, yr)
+    dx = ops.conv_dgrad_raw(cl(gy, dev), cl(w, dev), (B, Cin, Hh, Ww), k, s)
+    close(dx, xr.grad)
+    dw = ops.conv_wgrad_raw(cl(x, dev), cl(gy, dev), (Cout, Cin, k, k), k, s)
+    close(dw, wr.grad)
+
+
+def test_conv_fused_epilogue(dev):
+    from yolov4_amd import ops
+    B, Cin, Cout, k, s, Hh = 2, 64, 64, 3, 1, 11
+    x = recipe.randn((B, Cin, Hh, Hh), 4)
+    w = recipe.randn((Cout, Cin, k, k), 5, 0.05)
+    sc = recipe.rand((Cout,), 6) + 0.5
+    sh = recipe.randn((Cout,), 7)
+    res = recipe.randn((B, Cout, Hh, Hh), 8)
+    for act, fn in (('mish', NW.mish), ('leaky_relu', lambda t: F.leaky_relu(t, 0.1)), ('relu', F.relu), ('linear', lambda t: t)):
+        ref = fn(F.conv2d(x, w, None, s, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res
+        got = ops.conv_fwd_raw(cl(x, dev), cl(w, dev), k, s, sc.to(dev), sh.to(dev), act, cl(res, dev))
+        close(got, ref)
+
+
+def test_conv_output_into_channel_slice(dev):
+    """pixel pitch > C: conv reads a channel slice and writes a channel slice (zero-copy concat)"""
+    from yolov4_amd import ops
+    x = recipe.randn((2, 96, 8, 8), 9)
+    w = recipe.randn((64, 32, 1, 1), 10, 0.2)
+    xd = cl(x, dev)
+    buf = torch.zeros((2, 128, 8, 8), device=dev).contiguous(memory_format=torch.channels_last)
+    ops.conv_fwd_raw(xd[:, 32:64], cl(w, dev), 1, 1, out=buf[:, 64:128])
+    close(buf[:, 64:128], F.conv2d(x[:, 32:64], w))
+    assert float(buf[:, :64].abs().max()) == 0.0
+
+
+def test_stem_kernels(dev):
+    from yolov4_amd import ops
+    x = recipe.randn((3, 3, 37, 41), 11)
+    w = recipe.randn((32, 3, 3, 3), 12, 0.3)
+    xr = x.clone(); wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    gy = recipe.randn(tuple(yr.shape), 13)
+    yr.backward(gy)
+    for xin in (x.to(dev), cl(x, dev)):                      # NCHW as the reference feeds it, and NHWC
+        close(ops.conv_fwd_raw(xin, cl(w, dev), 3, 1), yr)
+        close(ops.conv_wgrad_raw(xin, cl(gy, dev), (32, 3, 3, 3), 3, 1), wr.grad)
+
+
+def test_conv_linearity_at_full_size(dev):
+    """Size-independent property at a BASELINE-size layer (128->128 3x3 @76x76, B=8):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2) within fp32 rounding."""
+    from yolov4_amd import ops
+    g = torch.Generator(device='cpu'); g.manual_seed(5)
+    x1 = torch.randn((8, 128, 76, 76), generator=g); x2 = torch.randn((8, 128, 76, 76), generator=g)
+    w = cl(torch.randn((128, 128, 3, 3), generator=g) * 0.03, dev)
+    y1 = ops.conv_fwd_raw(cl(x1, dev), w, 3, 1); y2 = ops.conv_fwd_raw(cl(x2, dev), w, 3, 1)
+    y12 = ops.conv_fwd_raw(cl(2.5 * x1 + x2, dev), w, 3, 1)
+    close(y12, 2.5 * y1 + y2, 2e-5, 1e-4)
+    # spot-check one output row against the CPU reference
+    ref = F.conv2d(x1[:1], w.cpu(), None, 1, 1)
+    close(y1[:1], ref)
+
+
+# ------------------------------------------------------------------ ConvBNAct / blocks against the reference's goldens
+def _load_cba(g, name, dev):
+    from yolov4_amd.darknet.darknet import ConvBNAct
+    cin, cout, k, s, bn, bias, B, Hh = [int(v) for v in g[f'{name}.cfg']]
+    m = ConvBNAct(cin, cout, k, s, bias=bool(bias), bn=bool(bn), act=str(g[f'{name}.act']))
+    sd = {kk[len(name) + 4:]: torch.from_numpy(g[kk].copy()) for kk in g.files if kk.startswith(name + '.sd.')}
+    m.load_state_dict(sd)
+    return m.to(dev)
+
+
+def test_convbnact_golden(dev, golden):
+    g = golden('convbnact')
+    for name in [str(n) for n in g['names']]:
+        m = _load_cba(g, name, dev)
+        x = torch.from_numpy(g[f'{name}.x'].copy()).to(dev)
+        m.eval()
+        with torch.no_grad():
+            close(m(x), g[f'{name}.eval_y'])
+        m.train()
+        is_stem = x.shape[1] == 3
+        xin = x.clone().requires_grad_(not is_stem)
+        y = m(xin)
+        close(y, g[f'{name}.train_y'])
+        y.backward(torch.from_numpy(g[f'{name}.gy'].copy()).to(dev))
+        if not is_stem:
+            close(xin.grad, g[f'{name}.gx'])
+        for kk in g.files:
+            if kk.startswith(name + '.grad.'):
+                p = dict(m.named_parameters())[kk[len(name) + 6:]]
+                close(p.grad, g[kk], 2e-4, 1e-3)
+            if kk.startswith(name + '.after.'):
+                close(m.state_dict()[kk[len(name) + 7:]], g[kk], 1e-5, 1e-4)
+
+
+def _fill(mod, seed, dev):
+    sd = mod.state_dict()
+    recipe.fill_state_dict_(sd, seed)
+    mod.load_state_dict(sd)
+    return mod.to(dev)
+
+
+def test_blocks_golden(dev, golden):
+    from yolov4_amd.darknet.darknet import CSPDownSample, CSPDownSample0, ResBlock
+    from yolov4_amd.yolo.model.yolov4 import SPPBlock, Upsample
+    g = golden('blocks')
+    cases = [('resblock', ResBlock(32, num_blocks=2), 601), ('csp0', CSPDownSample0(32, 64), 602),
+             ('csp', CSPDownSample(32, 64, num_blocks=2), 603), ('spp', SPPBlock(), 604)]
+    for name, mod, seed in cases:
+        mod = _fill(mod, seed, dev)
+        x = torch.from_numpy(g[f'{name}.x'].copy()).to(dev)
+        mod.train()
+        xin = x.clone().requires_grad_(True)
+        y = mod(xin)
+        close(y, g[f'{name}.train_y'])
+        y.backward(recipe.randn(tuple(y.shape), seed + 1).to(dev))
+        close(xin.grad, g[f'{name}.gx'], 2e-4, 1e-3)
+        named = dict(mod.named_parameters())
+        for kk, ref in zip([str(q) for q in g[f'{name}.gradnorm_keys']], g[f'{name}.gradnorm']):
+            got = float(named[kk].grad.double().norm())
+            assert abs(got - ref) <= 1e-3 * max(ref, 1e-3), (name, kk, got, ref)
+        mod.eval()
+        with torch.no_grad():
+            close(mod(x), g[f'{name}.eval_y'])
+    up = Upsample()
+    ux = torch.from_numpy(g['up.x'].copy()).to(dev)
+    close(up(ux, (2, 8, 6, 6)), g['up.train'], 0, 0)
+    uxg = ux.clone().requires_grad_(True)
+    gy = recipe.randn((2, 8, 6, 6), 99)
+    up(uxg, (2, 8, 6, 6)).backward(gy.to(dev))
+    close(uxg.grad, gy.view(2, 8, 3, 2, 3, 2).sum((3, 5)), 1e-6, 1e-6)
+
+
+def test_bn_statistics_large_mean(dev):
+    """E[y^2]-E[y]^2 is formed in fp64: a mean 30x the std must not destroy the variance."""
+    from yolov4_amd import ops
+    y = recipe.randn((8, 64, 40, 40), 21) * 0.5 + 15.0
+    mean, invstd = ops.bn_stats_raw(cl(y, dev), None, None, None, 0.1, 1e-5)
+    ref_m = y.double().mean((0, 2, 3)); ref_v = y.double().var((0, 2, 3), unbiased=False)
+    close(mean, ref_m, 1e-5, 1e-6)
+    close(invstd, 1.0 / torch.sqrt(ref_v + 1e-5), 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------ YOLO head
+@pytest.mark.parametrize('l', [0, 1, 2])
+def test_yololayer_golden(dev, golden, l):
+    from yolov4_amd.yolo.model.yololayer import YOLOLayer
+    g = golden('yololayer')
+    lay = YOLOLayer(CFG, l, device=dev)
+    x = torch.from_numpy(g[f'x{l}'].copy()).to(dev)
+    lay.train()
+    xin = x.clone().requires_grad_(True)
+    r = lay(xin)
+    assert r['layer_no'] == l
+    close(r['output'], g[f'train_output{l}'], 1e-6, 1e-6, scale=False)
+    close(r['pred'], g[f'train_pred{l}'], 1e-5, 1e-5)
+    go = recipe.randn(tuple(r['output'].shape), 200 + l).to(dev)
+    gp = recipe.randn(tuple(r['pred'].shape), 300 + l).to(dev)
+    ((r['output'] * go).sum() + (r['pred'] * gp).sum()).backward()
+    close(xin.grad, g[f'grad_x{l}'], 1e-5, 1e-4)
+    lay.eval()
+    with torch.no_grad():
+        close(lay(x), g[f'eval_out{l}'], 1e-5, 1e-5)
+
+
+def test_yololoss_golden(dev, golden):
+    from yolov4_amd.yolo.model.yololayer import YOLOLayer
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    g = golden('yololoss')
+    crit = YOLOLoss(CFG, ignore_thresh=0.7, device=dev)
+    labels = torch.from_numpy(g['labels'].copy())                      # float64 [B,60,5], as Transform emits
+    xs, outs = [], []
+    for l in range(3):
+        x = torch.from_numpy(g[f'logits{l}'].copy()).to(dev).requires_grad_(True)
+        lay = YOLOLayer(CFG, l, device=dev).train()
+        r = lay(x)
+        xs.append(x); outs.append(r)
+        tgt, obj, tm, ts = crit.build_target(r['output'], r['pred'], l, labels)
+        assert torch.equal(obj.cpu(), torch.from_numpy(g[f'obj_mask{l}']))          # bit-exact masks
+        assert torch.equal(tm[..., 0].cpu(), torch.from_numpy(g[f'tgt_mask{l}']))
+        assert bool((tm == tm[..., :1]).all())
+        assert torch.equal((tgt != 0).cpu(), torch.from_numpy(g[f'target{l}'] != 0))  # anchor / cell / class indices
+        close(tgt, g[f'target{l}'], 1e-6, 1e-6, scale=False)
+        close(ts, g[f'tgt_scale{l}'], 1e-6, 1e-6, scale=False)
+    for l in range(3):
+        lay = YOLOLayer(CFG, l, device=dev).train()
+        r = lay(torch.from_numpy(g[f'logits{l}'].copy()).to(dev))
+        ll = float(crit([r], {'padded_labels': labels}))
+        ref = float(g[f'loss_layer{l}'])
+        assert abs(ll - ref) <= 1e-4 * abs(ref), (l, ll, ref)
+    loss = crit(outs, {'padded_labels': labels})
+    ref = float(g['loss'])
+    assert abs(float(loss) - ref) <= 1e-4 * abs(ref)
+    loss.backward()
+    for l in range(3):
+        close(xs[l].grad, g[f'grad_logits{l}'], 1e-5, 1e-4)
+        close(outs[l]['output'], g[f'mutated_output{l}'], 1e-6, 1e-6, scale=False)   # the in-place side effect
+
+
+def test_postprocess_golden(dev, golden):
+    from yolov4_amd.yolo.util.utils import postprocess
+    g = golden('postprocess')
+    for case in range(2):
+        conf, thre = [float(v) for v in g[f'params{case}']]
+        for host in (False, True):
+            p = torch.from_numpy(g[f'pred{case}'].copy())
+            if not host:
+                p = p.to(dev)
+            out = postprocess(p, 80, conf, thre)
+            assert torch.equal(p[:, :, :4].cpu(), torch.from_numpy(g[f'xyxy{case}']))   # in-place xyxy, exact
+            for b in range(p.shape[0]):
+                if bool(g[f'isnone{case}_{b}']):
+                    assert out[b] is None
+                else:
+                    assert torch.equal(out[b].cpu(), torch.from_numpy(g[f'det{case}_{b}']))   # survivors + order: exact
+
+
+def test_nms_golden(dev, golden):
+    from yolov4_amd.yolo.util.utils import nms
+    g = golden('iou_nms')
+    assert np.array_equal(nms(g['box'], 0.45, score=g['score']), g['keep45'])
+    assert np.array_equal(nms(g['box'], 0.3, score=g['score'], limit=7), g['keep30_lim'])
+    assert np.array_equal(nms(g['box'], 0.5), g['keep_noscore'])
+    k = nms(np.zeros((0, 4), np.float32), 0.5, score=np.zeros((0,), np.float32))
+    assert k.shape == (0,) and k.dtype == np.int32
+    # defined tie order: equal scores -> lower index first
+    box = np.array([[0, 0, 10, 10], [100, 100, 110, 110], [0, 0, 10, 10]], np.float32)
+    assert nms(box, 0.5, score=np.array([0.5, 0.5, 0.5], np.float32)).tolist() == [0, 1]
+
+
+def test_postprocess_properties_full_size(dev):
+    """BASELINE-size input (N = 22743 boxes @608): survivor sets equal the oracle's on the
+    same input, NMS is idempotent, and nothing below the confidence threshold survives."""
+    from yolov4_amd.yolo.util.utils import postprocess
+    pred = recipe.synth_predictions(2, 22743, 31, n_clusters=150)
+    ref = H.postprocess(pred.numpy().copy(), 80, 0.4, 0.45)
+    out = postprocess(pred.clone().to(dev), 80, 0.4, 0.45)
+    for b in range(2):
+        assert np.array_equal(out[b].cpu().numpy(), ref[b])
+        d = out[b]
+        assert float((d[:, 4] * d[:, 5]).min()) >= 0.4
+        # idempotence: feed the survivors back (as xywh) -> the same set survives
+        again = torch.zeros((1, d.shape[0], 85), device=dev)
+        again[0, :, 0] = (d[:, 0] + d[:, 2]) / 2; again[0, :, 1] = (d[:, 1] + d[:, 3]) / 2
+        again[0, :, 2] = d[:, 2] - d[:, 0]; again[0, :, 3] = d[:, 3] - d[:, 1]
+        again[0, :, 4] = d[:, 4]
+        again[0, torch.arange(d.shape[0]), 5 + d[:, 6].long()] = d[:, 5]
+        o2 = postprocess(again, 80, 0.4, 0.45)[0]
+        assert o2.shape[0] == d.shape[0]
+        assert torch.equal(o2[:, 4:], d[:, 4:])
+
+
+# ------------------------------------------------------------------ whole model
+@pytest.fixture(scope='module')
+def hip_model(dev, golden):
+    from yolov4_amd.yolo.model.yolov4 import YOLOv4
+    m = YOLOv4(CFG, device=dev)
+    sd = m.state_dict()
+    recipe.fill_state_dict_(sd, int(golden('model')['seed']))
+    m.load_state_dict(sd)
+    return m.to(dev)
+
+
+def _reset(m, golden):
+    sd = m.state_dict()
+    cpu = {k: v.cpu() for k, v in sd.items()}
+    recipe.fill_state_dict_(cpu, int(golden('model')['seed']))
+    m.load_state_dict(cpu)
+
+
+def test_model_eval_golden(dev, golden, hip_model):
+    from yolov4_amd.yolo.util.utils import postprocess
+    g = golden('model')
+    m = hip_model
+    _reset(m, golden)
+    recipe.calibrate_bn_(m, recipe.randn((8, 3, 64, 64), 77).to(dev))
+    sd = m.state_dict()
+    for k in g.files:
+        if k.startswith('cal.'):
+            close(sd[k[4:]], g[k], 1e-4, 1e-3)
+    m.eval()
+    with torch.no_grad():
+        out = m(recipe.randn((2, 3, 64, 64), 78).to(dev))
+    ref = g['eval64.out']
+    close(out[..., 4:], ref[..., 4:], 1e-4, 1e-4, scale=False)     # obj / cls: abs 1e-4
+    close(out[..., :4], ref[..., :4], 1e-4, 1e-4)                 # boxes in px: 1e-4 of the box scale
+    det = postprocess(out.clone(), 80, 0.12, 0.4)
+    for b in range(2):
+        rd = g[f'eval64.det{b}']
+        assert det[b].shape == rd.shape
+        assert np.array_equal(det[b][:, 6].cpu().numpy(), rd[:, 6])
+        close(det[b], rd, 1e-4, 1e-4)
+    _reset(m, golden)
+    recipe.calibrate_bn_(m, recipe.randn((4, 3, 128, 128), 76).to(dev))
+    m.eval()
+    with torch.no_grad():
+        out = m(recipe.randn((1, 3, 128, 128), 79).to(dev))
+    ref = g['eval128.out']
+    close(out[..., 4:], ref[..., 4:], 1e-4, 1e-4, scale=False)
+    close(out[..., :4], ref[..., :4], 1e-4, 1e-4)
+
+
+def test_model_train_step_golden(dev, golden, hip_model):
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    g = golden('model')
+    m = hip_model
+    _reset(m, golden)
+    m.train()
+    m.zero_grad(set_to_none=True)
+    x = recipe.randn((2, 3, 128, 128), 80).to(dev)
+    labels = recipe.synth_labels(2, 128, 81, counts=[9, 21])
+    crit = YOLOLoss(CFG, ignore_thresh=0.7, device=dev, mutate_outputs=False)
+    outs = m(x)
+    for l in range(3):
+        close(outs[l]['output'], g[f'train128.output{l}'], 1e-4, 1e-4, scale=False)
+        close(outs[l]['pred'], g[f'train128.pred{l}'], 1e-4, 1e-4)
+    loss = crit(outs, {'padded_labels': labels})
+    ref = float(g['train128.loss'])
+    assert abs(float(loss) - ref) <= 1e-4 * ref
+    loss.backward()
+    named = dict(m.named_parameters())
+    for kk, refn in zip([str(q) for q in g['train128.gradnorm_keys']], g['train128.gradnorm']):
+        got = float(named[kk].grad.double().norm())
+        assert abs(got - refn) <= 2e-3 * max(refn, 1e-6), (kk, got, refn)
+    for k in g.files:
+        if k.startswith('train128.grad.'):
+            close(named[k[14:]].grad, g[k], 1e-3, 1e-3)
+        if k.startswith('train128.gradslice.'):
+            close(named[k[19:]].grad[:8, :16], g[k], 1e-3, 1e-3)
+        if k.startswith('train128.after.'):
+            close(m.state_dict()[k[15:]], g[k], 1e-5, 1e-4)
+
+
+def test_model_matches_oracle_at_608(dev, golden, hip_model):
+    """BASELINE resolution (608x608, B=1), train-mode statistics, against the oracle run on
+    the host here and now (no fixture: 22743 x 85 outputs)."""
+    m = hip_model
+    _reset(m, golden)
+    x = recipe.randn((1, 3, 608, 608), 123)
+    sd = NW.empty_state_dict()
+    recipe.fill_state_dict_(sd, int(golden('model')['seed']))
+    net = NW.RefNet(sd, CFG)
+    with torch.no_grad():
+        ref = net.forward_train(x)
+    m.train()
+    with torch.no_grad():
+        p1, p2, p3 = m.neck(*m.backbone(x.to(dev)))
+        lg = m.head.logits(p1, p2, p3)
+    for a, b in zip(lg, ref):
+        close(a, b, 2e-4, 1e-3)

@@ -1,0 +1,19 @@
+# -*- coding: utf-8 -*-
+"""yolov4_amd -- MI355X (gfx950) native forward/backward path for YOLOv4.
+
+Drop-in for the hot-path modules of zjykzj/YOLOv4:
+
+    reference import                              this package
+    darknet.darknet.ConvBNAct / ResBlock / ...    yolov4_amd.darknet.darknet
+    yolo.model.yolov4.YOLOv4                      yolov4_amd.yolo.model.yolov4
+    yolo.model.yololayer.YOLOLayer                yolov4_amd.yolo.model.yololayer
+    yolo.model.yololoss.YOLOLoss                  yolov4_amd.yolo.model.yololoss
+    yolo.model.build.build_model/build_criterion  yolov4_amd.yolo.model.build
+    yolo.util.utils.postprocess / nms             yolov4_amd.yolo.util.utils
+
+All arithmetic runs in libyolov4_amd.so (hand-written HIP, C ABI in
+include/yolov4_amd.h); there is no CPU or PyTorch-op fallback.
+"""
+from ._lib import LIB_PATH, Y4Error, lib  # noqa: F401
+
+__version__ = '0.1.0'

@@ -1,0 +1,59 @@
+// Shared device helpers for libyolov4_amd (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/yolov4_amd.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define Y4_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return Y4_ERR_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t y4_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// darknet/darknet.py:14-20: x * tanh(softplus(x)).  With n = e^x:
+// tanh(log(1+n)) = ((1+n)^2-1)/((1+n)^2+1) = n(n+2)/(n(n+2)+2); softplus threshold 20 of
+// torch (returns x above it) coincides with the ratio being exactly 1.0f there.
+__device__ __forceinline__ float y4_mish(float x) {
+    float n = expf(fminf(x, 20.0f));
+    float w = n * (n + 2.0f);
+    return x * (w / (w + 2.0f));
+}
+// d/dx [x * t(x)], t = tanh(softplus(x)):  t + x * (1 - t^2) * sigmoid(x)
+__device__ __forceinline__ float y4_mish_grad(float x) {
+    float n = expf(fminf(x, 20.0f));
+    float w = n * (n + 2.0f);
+    float d = w + 2.0f;
+    float t = w / d;
+    float omt2 = 4.0f * (w + 1.0f) / (d * d);      // 1 - t^2 without cancellation
+    float sg = n / (1.0f + n);
+    return t + x * omt2 * sg;
+}
+__device__ __forceinline__ float y4_act(float x, int act) {
+    switch (act) {
+        case Y4_ACT_LEAKY: return x > 0.0f ? x : 0.1f * x;
+        case Y4_ACT_MISH: return y4_mish(x);
+        case Y4_ACT_RELU: return fmaxf(x, 0.0f);
+        default: return x;
+    }
+}
+__device__ __forceinline__ float y4_act_grad(float x, int act) {
+    switch (act) {
+        case Y4_ACT_LEAKY: return x > 0.0f ? 1.0f : 0.1f;
+        case Y4_ACT_MISH: return y4_mish_grad(x);
+        case Y4_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
+        default: return 1.0f;
+    }
+}
+
+// XCD-aware block remap (MI355X: 8 XCDs, blocks dealt round-robin, private L2 each): give every
+// XCD a contiguous chunk of the logical tile sequence so neighbouring tiles (shared halo rows /
+// shared filter panels) hit the same L2.  Bijective for any nwg (guide §5 "XCD swizzle").
+__device__ __forceinline__ int y4_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

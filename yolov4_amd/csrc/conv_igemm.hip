@@ -1,0 +1,663 @@
+// Implicit-GEMM convolution for gfx950 on v_mfma_f32_32x32x2_f32 (exact fp32, fp32 accumulate).
+//
+//   forward / dgrad ("gather" kernel):  D[m][n] = sum_k A[m][k] * Bt[n][k]
+//       m = output pixel (b,ho,wo), n = output channel, k = (r,q,c)
+//       A is gathered on the fly from the NHWC activation (never materialised),
+//       Bt is the KRSC filter read as a row-major [N][K] matrix.
+//   wgrad:                              D[n][j] = sum_p dy[p][n] * xg[p][j]
+//       p = output pixel, j = (r,q,c); both operands are K-major (pixel-major) as stored.
+//
+// Tile: 256 threads = 4 waves; each wave owns TM x TN tiles of 32x32 (16 accumulator VGPRs each).
+// LDS: [rows][BK + 4] floats (row pitch 144 B -> ds_read_b128 conflict-free across the 16-lane
+// groups), double buffered, register-staged global loads issued one K-tile ahead.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;            // K-tile depth (floats)
+constexpr int LDS_PITCH = BK + 4; // padded row pitch (floats): 36*4 = 144 B
+
+struct ConvGeom {
+    // gathered ("source") tensor and produced ("dest") tensor, both NHWC with pitch
+    const float* src; const float* wt; float* dst;
+    const float* scale; const float* shift; const float* res;
+    long long lds_, ldd, ldr;     // pixel pitches (elements)
+    int B, Hs, Ws, Cs;            // source dims (Cs = GEMM-K channels, multiple of 32)
+    int Cs_valid;                 // channels >= Cs_valid of the source are treated as zero (pad lanes)
+    int Hd, Wd, N;                // dest spatial dims, N = dest channels (any)
+    int k, stride, pad;
+    int M;                        // B*Hd*Wd
+    int K;                        // k*k*Cs
+    int act;
+    int mtiles, ntiles;
+};
+
+// TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
+// TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
+//                     valid only when both divisions are exact.
+template <int BM, int BN, int WM, int WN, bool TRANSPOSED>
+__global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g) {
+    constexpr int PA = BM / 32, PB = BN / 32;         // load passes (32 rows x 8 lanes x 16 B per pass)
+    constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [2][BM][LDS_PITCH]
+    float* Bs = smem + 2 * BM * LDS_PITCH;             // [2][BN][LDS_PITCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // logical tile: N-tiles innermost so the blocks of one XCD chunk reuse the same A panel
+    const int nwg = g.mtiles * g.ntiles;
+    const int lt = y4_xcd_remap(blockIdx.x, nwg);
+    const int mt = lt / g.ntiles, nt = lt - mt * g.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int lrow = tid >> 3, kc = tid & 7;
+
+    // ---- per-thread A-row bookkeeping (rows are fixed for the whole K loop)
+    long long a_base[PA];
+    int a_h[PA], a_w[PA];
+    bool a_ok[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int m = m0 + p * 32 + lrow;
+        a_ok[p] = m < g.M;
+        const int mm = a_ok[p] ? m : 0;
+        const int b = mm / (g.Hd * g.Wd);
+        const int rem = mm - b * (g.Hd * g.Wd);
+        const int hd = rem / g.Wd, wd = rem - hd * g.Wd;
+        if (!TRANSPOSED) {
+            a_h[p] = hd * g.stride - g.pad;
+            a_w[p] = wd * g.stride - g.pad;
+            a_base[p] = (((long long)b * g.Hs + a_h[p]) * g.Ws + a_w[p]) * g.lds_ + kc * 4;
+        } else {
+            a_h[p] = hd + g.pad;
+            a_w[p] = wd + g.pad;
+            a_base[p] = (long long)b * g.Hs * g.Ws * g.lds_ + kc * 4;
+        }
+    }
+    // ---- per-thread B rows
+    const float* b_ptr[PB];
+    bool b_ok[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int n = n0 + p * 32 + lrow;
+        b_ok[p] = n < g.N;
+        b_ptr[p] = g.wt + (long long)(b_ok[p] ? n : 0) * g.K + kc * 4;
+    }
+
+    f32x4 ra[PA], rb[PB];
+    const int CC = g.Cs / BK;
+    int r = 0, q = 0, cc = 0;     // position of the K-tile being LOADED
+
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            bool ok = a_ok[p];
+            long long off;
+            if (!TRANSPOSED) {
+                const int hi = a_h[p] + r, wi = a_w[p] + q;
+                ok = ok && (unsigned)hi < (unsigned)g.Hs && (unsigned)wi < (unsigned)g.Ws;
+                off = a_base[p] + ((long long)r * g.Ws + q) * g.lds_ + cc * BK;
+            } else {
+                const int th = a_h[p] - r, tw = a_w[p] - q;
+                int hi, wi;
+                if (g.stride == 1) { hi = th; wi = tw; }
+                else { ok = ok && ((th | tw) & 1) == 0; hi = th >> 1; wi = tw >> 1; }
+                ok = ok && th >= 0 && tw >= 0 && hi < g.Hs && wi < g.Ws;
+                off = a_base[p] + ((long long)hi * g.Ws + wi) * g.lds_ + cc * BK;
+            }
+            ra[p] = ok ? *reinterpret_cast<const f32x4*>(g.src + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (TRANSPOSED) {     // dy may carry pad channels (Cout = 255 -> 256) with undefined content
+                const int c = cc * BK + kc * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e >= g.Cs_valid) ra[p][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            rb[p] = b_ok[p] ? *reinterpret_cast<const f32x4*>(b_ptr[p] + (long long)kt * BK)
+                            : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (++cc == CC) { cc = 0; if (++q == g.k) { q = 0; ++r; } }
+    };
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * BM * LDS_PITCH;
+        float* bs = Bs + buf * BN * LDS_PITCH;
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<f32x4*>(as + (p * 32 + lrow) * LDS_PITCH + kc * 4) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<f32x4*>(bs + (p * 32 + lrow) * LDS_PITCH + kc * 4) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int KT = g.k * g.k * CC;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int a_frag = (wm * WTM + fr) * LDS_PITCH + fh * 4;
+    const int b_frag = (wn * WTN + fr) * LDS_PITCH + fh * 4;
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);            // global loads in flight under the MFMAs
+        const float* as = As + cur * BM * LDS_PITCH + a_frag;
+        const float* bs = Bs + cur * BN * LDS_PITCH + b_frag;
+#pragma unroll
+        for (int u = 0; u < BK / 8; ++u) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_PITCH + u * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LDS_PITCH + u * 8);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + fr;
+        const bool nok = n < g.N;
+        const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
+        const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mbase = m0 + wm * WTM + i * 32 + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mbase + (e & 3) + 8 * (e >> 2);
+                if (nok && m < g.M) {
+                    float v = acc[i][j][e] * sc + sh;
+                    v = y4_act(v, g.act);
+                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    g.dst[(long long)m * g.ldd + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// [Cout][k][k][Cin] -> [Cin][k][k][Cout4] (zero padded to a multiple of 32 output channels)
+__global__ void transpose_filter_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                        int Cout, int Cin, int kk, int Cout_pad) {
+    const long long total = (long long)Cin * kk * Cout_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Cout_pad);
+        const long long t = i / Cout_pad;
+        const int tap = (int)(t % kk);
+        const int c = (int)(t / kk);
+        wt[i] = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool TR>
+int launch_gather(const ConvGeom& g0, hipStream_t st) {
+    ConvGeom g = g0;
+    g.mtiles = (g.M + BM - 1) / BM;
+    g.ntiles = (g.N + BN - 1) / BN;
+    const size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float);
+    auto kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(256), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+template <bool TR>
+int dispatch_gather(const ConvGeom& g, hipStream_t st) {
+    if (g.N > 64) return launch_gather<128, 128, 2, 2, TR>(g, st);
+    if (g.N > 32) return launch_gather<128, 64, 2, 2, TR>(g, st);
+    return launch_gather<128, 32, 4, 1, TR>(g, st);
+}
+
+// ------------------------------------------------------------------------------------ wgrad
+struct WgradGeom {
+    const float* x; const float* dy; float* out;    // out: dw (splits==1) or slab base
+    long long ldx, lddy;
+    int B, H, W, Cin, Ho, Wo, Cout;
+    int k, stride, pad;
+    int M;          // B*Ho*Wo
+    int J;          // k*k*Cin
+    int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
+};
+
+constexpr int WG_T = 128;        // tile edge (n and j)
+constexpr int WG_PITCH = WG_T;   // k-major rows of 128 floats; ds_read_b32 across a half-wave is conflict-free
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                           // [2][32][128]  dy tile   (pixel-major)
+    float* Bs = smem + 2 * 32 * WG_PITCH;       // [2][32][128]  x  tile   (pixel-major)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int bid = blockIdx.x;
+    const int split = bid / (g.ntn * g.ntj);
+    bid -= split * (g.ntn * g.ntj);
+    const int tn = bid / g.ntj, tj = bid - tn * g.ntj;
+    const int n0 = tn * WG_T, j0 = tj * WG_T;
+
+    // loader mapping: 8 pixel rows per pass, 32 lanes x 16 B per row; 4 passes
+    const int prow = tid >> 5, c4 = (tid & 31) * 4;
+    const int Cout4 = (g.Cout + 3) & ~3;
+    const bool an_ok = (n0 + c4) < Cout4;
+    const int j = j0 + c4;
+    const bool bj_ok = j < g.J;
+    int jr = 0, jq = 0, jc = 0;
+    if (bj_ok) { const int tap = j / g.Cin; jc = j - tap * g.Cin; jr = tap / g.k; jq = tap - jr * g.k; }
+
+    const int chunk0 = split * g.chunks_per_split;
+    int nchunks = (g.M + 31) / 32 - chunk0;
+    if (nchunks > g.chunks_per_split) nchunks = g.chunks_per_split;
+
+    f32x4 ra[4], rb[4];
+    auto load_chunk = [&](int ch) {
+        const int pbase = (chunk0 + ch) * 32;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int pix = pbase + p * 8 + prow;
+            const bool pok = pix < g.M;
+            ra[p] = (pok && an_ok) ? *reinterpret_cast<const f32x4*>(g.dy + (long long)pix * g.lddy + n0 + c4)
+                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+            bool ok = pok && bj_ok;
+            long long off = 0;
+            if (ok) {
+                const int b = pix / (g.Ho * g.Wo);
+                const int rem = pix - b * (g.Ho * g.Wo);
+                const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+                const int hi = ho * g.stride - g.pad + jr, wi = wo * g.stride - g.pad + jq;
+                ok = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                off = (((long long)b * g.H + hi) * g.W + wi) * g.ldx + jc;
+            }
+            rb[p] = ok ? *reinterpret_cast<const f32x4*>(g.x + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<f32x4*>(As + (buf * 32 + p * 8 + prow) * WG_PITCH + c4) = ra[p];
+            *reinterpret_cast<f32x4*>(Bs + (buf * 32 + p * 8 + prow) * WG_PITCH + c4) = rb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_chunk(0);
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int cur = ch & 1;
+            if (ch + 1 < nchunks) load_chunk(ch + 1);
+            const float* as = As + (cur * 32 + fh) * WG_PITCH + wm * 64 + fr;
+            const float* bs = Bs + (cur * 32 + fh) * WG_PITCH + wn * 64 + fr;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float a0 = as[(2 * t) * WG_PITCH], a1 = as[(2 * t) * WG_PITCH + 32];
+                const float b0 = bs[(2 * t) * WG_PITCH], b1 = bs[(2 * t) * WG_PITCH + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (ch + 1 < nchunks) store_chunk(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // D[n][j]: row index (n) on the registers, column (j) on the lane
+    float* out = g.out + (long long)split * g.Cout * g.J;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int jcol = j0 + wn * 64 + jj * 32 + fr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int nb = n0 + wm * 64 + i * 32 + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = nb + (e & 3) + 8 * (e >> 2);
+                if (n < g.Cout && jcol < g.J) out[(long long)n * g.J + jcol] = acc[i][jj][e];
+            }
+        }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                   long long n, int splits) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];   // fixed order
+        out[i] = s;
+    }
+}
+
+void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int stride, WgradGeom& g) {
+    const int pad = (k - 1) / 2;
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.stride = stride; g.pad = pad;
+    g.Ho = (H + 2 * pad - k) / stride + 1;
+    g.Wo = (W + 2 * pad - k) / stride + 1;
+    g.M = B * g.Ho * g.Wo;
+    g.J = k * k * Cin;
+    g.ntn = (Cout + WG_T - 1) / WG_T;
+    g.ntj = (g.J + WG_T - 1) / WG_T;
+    const int tiles = g.ntn * g.ntj;
+    const int chunks = (g.M + 31) / 32;
+    int splits = (1024 + tiles - 1) / tiles;           // aim at ~4 blocks per CU
+    const int max_splits = (chunks + 7) / 8;           // >= 8 chunks (256 pixels) per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    g.chunks_per_split = (chunks + splits - 1) / splits;
+    g.splits = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
+}
+
+// ------------------------------------------------------------------------------------ stem
+// Cin = 3, k = 3, stride 1, pad 1 (yolo/model/yolov4.py:30).  One thread per output pixel, all
+// Cout (<= 32) channels in registers, filter taps come in through the scalar path (uniform
+// addresses); the 128-B pixel rows are transposed through LDS so stores are lane-contiguous.
+struct StemGeom {
+    const float* x; const float* w; float* y; const float* scale; const float* shift;
+    long long sxb, sxc, sxh, sxw, ldy;
+    int B, H, W, Cout, act;
+    long long M;
+};
+
+__global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemGeom g) {
+    __shared__ float tile[4][64][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long pix0 = (long long)blockIdx.x * 256 + wave * 64;
+    const long long pix = pix0 + lane;
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+    if (pix < g.M) {
+        const int b = (int)(pix / ((long long)g.H * g.W));
+        const int rem = (int)(pix - (long long)b * g.H * g.W);
+        const int h = rem / g.W, w = rem - h * g.W;
+        const float* xb = g.x + b * g.sxb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int hi = h + r - 1, wi = w + q - 1;
+                const bool ok = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float v = ok ? xb[c * g.sxc + hi * g.sxh + wi * g.sxw] : 0.f;
+                    const float* wp = g.w + (r * 3 + q) * 3 + c;          // w[n][r][q][c], n stride 27
+#pragma unroll
+                    for (int n = 0; n < 32; ++n)
+                        if (n < g.Cout) acc[n] = fmaf(v, wp[n * 27], acc[n]);
+                }
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+        float v = acc[n];
+        if (n < g.Cout) {
+            v = v * (g.scale ? g.scale[n] : 1.f) + (g.shift ? g.shift[n] : 0.f);
+            v = y4_act(v, g.act);
+        }
+        tile[wave][lane][n] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // 64 pixels x 32 ch: lane -> (pixel = it*2 + lane/32, ch = lane%32): 128-B contiguous per half wave
+    const int ch = lane & 31;
+    if (ch < g.Cout) {
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const int pl = it * 2 + (lane >> 5);
+            const long long p = pix0 + pl;
+            if (p < g.M) g.y[p * g.ldy + ch] = tile[wave][pl][ch];
+        }
+    }
+}
+
+// wgrad of the stem: D[n][j] (32 x 27->32) = sum_p dy[p][n] * x[p + tap(j)][c(j)], operands
+// straight from global memory into the MFMA (a dy pixel row IS the 32-float A fragment).
+struct StemWgradGeom {
+    const float* x; const float* dy; float* slabs;
+    long long sxb, sxc, sxh, sxw, lddy;
+    int B, H, W, Cout;
+    long long M, pix_per_wave;
+};
+
+__global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradGeom g) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const long long wave_id = (long long)blockIdx.x * 4 + (tid >> 6);
+    const long long p_begin = wave_id * g.pix_per_wave;
+    long long p_end = p_begin + g.pix_per_wave;
+    if (p_end > g.M) p_end = g.M;
+    const int fr = lane & 31, fh = lane >> 5;
+    const bool jok = fr < 27;
+    const int tap = jok ? fr / 3 : 0, c = jok ? fr - tap * 3 : 0;
+    const int r = tap / 3 - 1, q = tap - (tap / 3) * 3 - 1;
+    const bool nok = fr < g.Cout;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (long long p = p_begin + fh; p < p_end + fh; p += 2) {      // both halves iterate the same count
+        float a = 0.f, bv = 0.f;
+        if (p < p_end) {
+            if (nok) a = g.dy[p * g.lddy + fr];
+            if (jok) {
+                const int b = (int)(p / ((long long)g.H * g.W));
+                const int rem = (int)(p - (long long)b * g.H * g.W);
+                const int h = rem / g.W, w = rem - h * g.W;
+                const int hi = h + r, wi = w + q;
+                if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+                    bv = g.x[b * g.sxb + c * g.sxc + hi * g.sxh + wi * g.sxw];
+            }
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+    }
+    float* out = g.slabs + wave_id * 1024;     // [32 n][32 j]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int n = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        out[n * 32 + fr] = acc[e];
+    }
+}
+
+__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                         int nslabs, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over Cout*27
+    if (i >= Cout * 27) return;
+    const int n = i / 27, j = i - n * 27;
+    double s = 0.0;
+    for (int k = 0; k < nslabs; ++k) s += (double)slabs[(long long)k * 1024 + n * 32 + j];
+    dw[i] = (float)s;
+}
+
+constexpr int STEM_WAVES = 4096;
+
+}  // namespace
+
+// ======================================================================================== C ABI
+extern "C" {
+
+int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
+                      int B, int H, int W, int Cin, int Cout, int k, int stride,
+                      const float* scale, const float* shift, int act,
+                      const float* residual, int ldr, void* stream) {
+    if (!x || !w || !y) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
+        return Y4_ERR_SHAPE;
+    if (Cin <= 0 || Cin % BK != 0 || ldx < Cin || ldy < Cout || (ldx & 3) || (residual && ldr < Cout))
+        return Y4_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) return Y4_ERR_SHAPE;
+    const int pad = (k - 1) / 2;
+    ConvGeom g{};
+    g.src = x; g.wt = w; g.dst = y; g.scale = scale; g.shift = shift; g.res = residual;
+    g.lds_ = ldx; g.ldd = ldy; g.ldr = ldr;
+    g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cin; g.Cs_valid = Cin;
+    g.Hd = (H + 2 * pad - k) / stride + 1;
+    g.Wd = (W + 2 * pad - k) / stride + 1;
+    g.N = Cout; g.k = k; g.stride = stride; g.pad = pad;
+    const long long M = (long long)B * g.Hd * g.Wd;
+    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
+    g.M = (int)M; g.K = k * k * Cin; g.act = act;
+    return dispatch_gather<false>(g, y4_stream(stream));
+}
+
+size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
+    const size_t cp = (size_t)((Cout + 31) / 32) * 32;
+    return (size_t)Cin * k * k * cp * sizeof(float);
+}
+
+int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                        int B, int H, int W, int Cin, int Cout, int k, int stride,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
+        return Y4_ERR_SHAPE;
+    const int Cout_pad = (Cout + 31) / 32 * 32;
+    // the padded channels of dy are read (multiplied by zero filter rows): they must exist
+    if (lddy < Cout_pad || (lddy & 3) || lddx < Cin) return Y4_ERR_SHAPE;
+    if (workspace_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(dy) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return Y4_ERR_SHAPE;
+    hipStream_t st = y4_stream(stream);
+    float* wt = static_cast<float*>(workspace);
+    const long long total = (long long)Cin * k * k * Cout_pad;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(transpose_filter_kernel, dim3(blocks), dim3(256), 0, st, w, wt, Cout, Cin, k * k, Cout_pad);
+    Y4_CHECK_LAUNCH();
+    const int pad = (k - 1) / 2;
+    ConvGeom g{};
+    g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = nullptr;
+    g.lds_ = lddy; g.ldd = lddx; g.ldr = 0;
+    g.B = B;
+    g.Hs = (H + 2 * pad - k) / stride + 1;
+    g.Ws = (W + 2 * pad - k) / stride + 1;
+    g.Cs = Cout_pad; g.Cs_valid = Cout;
+    g.Hd = H; g.Wd = W; g.N = Cin; g.k = k; g.stride = stride; g.pad = pad;
+    const long long M = (long long)B * H * W;
+    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
+    g.M = (int)M; g.K = k * k * Cout_pad; g.act = Y4_ACT_LINEAR;
+    return dispatch_gather<true>(g, st);
+}
+
+size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+    WgradGeom g{};
+    wgrad_plan(B, H, W, Cin, Cout, k, stride, g);
+    return g.splits > 1 ? (size_t)g.splits * Cout * g.J * sizeof(float) : 16;
+}
+
+int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                        int B, int H, int W, int Cin, int Cout, int k, int stride,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
+        return Y4_ERR_SHAPE;
+    if (Cin <= 0 || (Cin & 3) || ldx < Cin || (ldx & 3) || (lddy & 3) || lddy < ((Cout + 3) & ~3)) return Y4_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return Y4_ERR_SHAPE;
+    WgradGeom g{};
+    wgrad_plan(B, H, W, Cin, Cout, k, stride, g);
+    if ((long long)B * g.Ho * g.Wo >= (1ll << 31)) return Y4_ERR_SHAPE;
+    g.x = x; g.dy = dy; g.ldx = ldx; g.lddy = lddy;
+    hipStream_t st = y4_stream(stream);
+    if (g.splits > 1) {
+        if (!workspace) return Y4_ERR_NULL;
+        if (workspace_bytes < (size_t)g.splits * Cout * g.J * sizeof(float)) return Y4_ERR_WORKSPACE;
+        g.out = static_cast<float*>(workspace);
+    } else {
+        g.out = dw;
+    }
+    const size_t smem = 2ull * 2 * 32 * WG_PITCH * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_mfma_f32),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_mfma_f32, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    if (g.splits > 1) {
+        const long long n = (long long)Cout * g.J;
+        const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st,
+                           static_cast<const float*>(workspace), dw, n, g.splits);
+        Y4_CHECK_LAUNCH();
+    }
+    return Y4_OK;
+}
+
+int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
+                           const float* w, float* y, int ldy, int B, int H, int W, int Cout,
+                           const float* scale, const float* shift, int act, void* stream) {
+    if (!x || !w || !y) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 32 || ldy < Cout) return Y4_ERR_SHAPE;
+    StemGeom g{};
+    g.x = x; g.w = w; g.y = y; g.scale = scale; g.shift = shift;
+    g.sxb = sxb; g.sxc = sxc; g.sxh = sxh; g.sxw = sxw; g.ldy = ldy;
+    g.B = B; g.H = H; g.W = W; g.Cout = Cout; g.act = act;
+    g.M = (long long)B * H * W;
+    const long long blocks = (g.M + 255) / 256;
+    if (blocks >= (1ll << 31)) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(conv_stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, y4_stream(stream), g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+size_t y4_conv2d_stem_wgrad_workspace(int, int, int, int) { return (size_t)STEM_WAVES * 1024 * sizeof(float); }
+
+int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
+                             const float* dy, int lddy, float* dw, int B, int H, int W, int Cout,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || !workspace) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 32 || lddy < Cout) return Y4_ERR_SHAPE;
+    if (workspace_bytes < y4_conv2d_stem_wgrad_workspace(B, H, W, Cout)) return Y4_ERR_WORKSPACE;
+    StemWgradGeom g{};
+    g.x = x; g.dy = dy; g.slabs = static_cast<float*>(workspace);
+    g.sxb = sxb; g.sxc = sxc; g.sxh = sxh; g.sxw = sxw; g.lddy = lddy;
+    g.B = B; g.H = H; g.W = W; g.Cout = Cout;
+    g.M = (long long)B * H * W;
+    long long ppw = (g.M + STEM_WAVES - 1) / STEM_WAVES;
+    ppw = (ppw + 1) & ~1ll;                       // even, so MFMA pixel pairs never straddle waves
+    g.pix_per_wave = ppw;
+    hipStream_t st = y4_stream(stream);
+    hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(STEM_WAVES / 4), dim3(256), 0, st, g);
+    Y4_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((Cout * 27 + 255) / 256), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), dw, STEM_WAVES, Cout);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+}  // extern "C"

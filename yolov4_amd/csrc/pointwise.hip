@@ -1,0 +1,547 @@
+// HBM-bound kernels around the convolutions: BatchNorm statistics / apply / backward fused with
+// the activation (and the ResBlock skip), channel concat copies, gradient fan-in adds, SPP max
+// pools, nearest x2 upsample.  All NHWC fp32 with an explicit pixel pitch, 16-B vector access
+// (C % 4 == 0, pitch % 4 == 0, 16-B aligned bases), one channel-vector per thread so the
+// per-channel constants live in registers for the whole row sweep.
+#include "common.h"
+
+namespace {
+
+constexpr int PW_THREADS = 256;
+
+struct RowMap {            // thread -> (channel vector, row group)
+    int tpr;               // threads per row (channel vectors handled concurrently)
+    int rpb;               // rows per block iteration
+};
+static inline RowMap row_map(int C) {
+    RowMap r;
+    int c4 = C / 4;
+    r.tpr = c4 < PW_THREADS ? c4 : PW_THREADS;
+    // tpr must divide 256: C/4 in {8,16,32,64,128,256,...}; otherwise fall back to the largest
+    // power of two <= c4 and loop the remainder
+    int p = 1;
+    while (p * 2 <= r.tpr) p *= 2;
+    r.tpr = p;
+    r.rpb = PW_THREADS / r.tpr;
+    return r;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---------------------------------------------------------------- BN statistics
+// Each thread sums <= ROWS_PER_THREAD rows in fp32, the block folds row groups through LDS and
+// issues one fp64 atomic per channel: var = E[y^2] - E[y]^2 is formed in fp64.
+constexpr int STAT_ROWS_PER_THREAD = 128;
+
+__global__ __launch_bounds__(PW_THREADS) void bn_stats_kernel(const float* __restrict__ y, long long ldy,
+                                                              long long M, int C, int tpr, int rpb,
+                                                              double* __restrict__ acc /* [2][C] */) {
+    __shared__ float red[2][PW_THREADS][4];
+    const int tid = threadIdx.x;
+    const int cv = tid % tpr, rg = tid / tpr;
+    const long long row0 = (long long)blockIdx.x * rpb * STAT_ROWS_PER_THREAD;
+    for (int cb = 0; cb < C; cb += tpr * 4) {           // uniform trip count: barriers inside
+        const int c0 = cb + cv * 4;
+        const bool cok = c0 < C;
+        f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+#pragma unroll 4
+        for (int i = 0; i < STAT_ROWS_PER_THREAD; ++i) {
+            const long long m = row0 + (long long)i * rpb + rg;
+            if (m < M && cok) {
+                const f32x4 v = ld4(y + m * ldy + c0);
+                s += v;
+                ss += v * v;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = ss[e]; }
+        __syncthreads();
+        if (rg == 0 && cok) {
+            double ds[4] = {0, 0, 0, 0}, dss[4] = {0, 0, 0, 0};
+            for (int g = 0; g < rpb; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ds[e] += (double)red[0][g * tpr + cv][e];
+                    dss[e] += (double)red[1][g * tpr + cv][e];
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&acc[c0 + e], ds[e]);
+                atomicAdd(&acc[C + c0 + e], dss[e]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, long long M, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) *nbt += 1;
+    if (c >= C) return;
+    const double mu = acc[c] / (double)M;
+    double var = acc[C + c] / (double)M - mu * mu;
+    if (var < 0) var = 0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mu;
+    if (rvar) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+// ---------------------------------------------------------------- BN apply + act (+ skip)
+__global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
+    const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    const float* __restrict__ res, long long ldr, float* __restrict__ z, long long ldz,
+    long long M, int C, int tpr, int rpb) {
+    const int tid = threadIdx.x;
+    const int cv = tid % tpr, rg = tid / tpr;
+    for (int c0 = cv * 4; c0 < C; c0 += tpr * 4) {
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = invstd[c0 + e] * gamma[c0 + e];
+            b[e] = beta[c0 + e] - mean[c0 + e] * a[e];
+        }
+        for (long long m = (long long)blockIdx.x * rpb + rg; m < M; m += (long long)gridDim.x * rpb) {
+            f32x4 v = ld4(y + m * ldy + c0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = y4_act(v[e] * a[e] + b[e], act);
+            if (res) o += ld4(res + m * ldr + c0);
+            st4(z + m * ldz + c0, o);
+        }
+    }
+}
+
+// backward pass 1: sum_g[c] = sum_m g, sum_gx[c] = sum_m g * xhat,  g = dz * act'(u)
+__global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
+    const float* __restrict__ dz, long long lddz, const float* __restrict__ y, long long ldy,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    long long M, int C, int tpr, int rpb, double* __restrict__ acc) {
+    __shared__ float red[2][PW_THREADS][4];
+    const int tid = threadIdx.x;
+    const int cv = tid % tpr, rg = tid / tpr;
+    const long long row0 = (long long)blockIdx.x * rpb * STAT_ROWS_PER_THREAD;
+    for (int cb = 0; cb < C; cb += tpr * 4) {           // uniform trip count: barriers inside
+        const int c0 = cb + cv * 4;
+        const bool cok = c0 < C;
+        f32x4 mu = {0, 0, 0, 0}, is = mu, ga = mu, be = mu;
+        if (cok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; }
+        }
+        f32x4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
+#pragma unroll 2
+        for (int i = 0; i < STAT_ROWS_PER_THREAD; ++i) {
+            const long long m = row0 + (long long)i * rpb + rg;
+            if (m < M && cok) {
+                const f32x4 v = ld4(y + m * ldy + c0);
+                const f32x4 d = ld4(dz + m * lddz + c0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (v[e] - mu[e]) * is[e];
+                    const float g = d[e] * y4_act_grad(ga[e] * xh + be[e], act);
+                    s[e] += g;
+                    sx[e] += g * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = sx[e]; }
+        __syncthreads();
+        if (rg == 0 && cok) {
+            double ds[4] = {0, 0, 0, 0}, dsx[4] = {0, 0, 0, 0};
+            for (int g = 0; g < rpb; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ds[e] += (double)red[0][g * tpr + cv][e];
+                    dsx[e] += (double)red[1][g * tpr + cv][e];
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(&acc[c0 + e], ds[e]);
+                atomicAdd(&acc[C + c0 + e], dsx[e]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)acc[c];
+    dgamma[c] = (float)acc[C + c];
+}
+
+// backward pass 2: dy = gamma*invstd * (g - sum_g/M - xhat * sum_gx/M)
+__global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
+    const float* __restrict__ dz, long long lddz, const float* __restrict__ y, long long ldy,
+    const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+    const double* __restrict__ acc, float* __restrict__ dy, long long lddy,
+    long long M, int C, int tpr, int rpb) {
+    const int tid = threadIdx.x;
+    const int cv = tid % tpr, rg = tid / tpr;
+    const double invM = 1.0 / (double)M;
+    for (int c0 = cv * 4; c0 < C; c0 += tpr * 4) {
+        f32x4 mu, is, ga, be, k1, k2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e];
+            k1[e] = (float)(acc[c0 + e] * invM);
+            k2[e] = (float)(acc[C + c0 + e] * invM);
+        }
+        for (long long m = (long long)blockIdx.x * rpb + rg; m < M; m += (long long)gridDim.x * rpb) {
+            const f32x4 v = ld4(y + m * ldy + c0);
+            const f32x4 d = ld4(dz + m * lddz + c0);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (v[e] - mu[e]) * is[e];
+                const float g = d[e] * y4_act_grad(ga[e] * xh + be[e], act);
+                o[e] = ga[e] * is[e] * (g - k1[e] - xh * k2[e]);
+            }
+            st4(dy + m * lddy + c0, o);
+        }
+    }
+}
+
+__global__ __launch_bounds__(PW_THREADS) void colsum_kernel(const float* __restrict__ x, long long ldx, long long M,
+                                                            int C, double* __restrict__ acc) {
+    // generic column sums (C arbitrary, scalar loads): dbias of the 255-channel head convs
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const long long rows_per_block = 256;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    float s = 0.f;
+    for (long long m = r0; m < r0 + rows_per_block && m < M; ++m) s += x[m * ldx + c];
+    atomicAdd(&acc[c], (double)s);
+}
+__global__ void colsum_finalize_kernel(const double* __restrict__ acc, int C, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) out[c] = (float)acc[c];
+}
+
+__global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                               float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = s;
+    shift[c] = beta[c] - rm[c] * s;
+}
+
+// ---------------------------------------------------------------- copies / adds
+__global__ __launch_bounds__(PW_THREADS) void copy_rows_kernel(const float* __restrict__ src, long long lds_,
+                                                               float* __restrict__ dst, long long ldd,
+                                                               long long M, int C4) {
+    const long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C4;
+        const int c = (int)(i - m * C4) * 4;
+        st4(dst + m * ldd + c, ld4(src + m * lds_ + c));
+    }
+}
+__global__ __launch_bounds__(PW_THREADS) void add_rows_kernel(const float* a, long long lda, const float* b,
+                                                              long long ldb, float* out, long long ldo,
+                                                              long long M, int C4) {
+    const long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C4;
+        const int c = (int)(i - m * C4) * 4;
+        st4(out + m * ldo + c, ld4(a + m * lda + c) + ld4(b + m * ldb + c));
+    }
+}
+
+// ---------------------------------------------------------------- max pool (stride 1, same pad)
+__global__ __launch_bounds__(PW_THREADS) void maxpool_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                                 float* __restrict__ y, long long ldy,
+                                                                 signed char* __restrict__ idx,
+                                                                 int B, int H, int W, int C4, int ks) {
+    const long long total = (long long)B * H * W * C4;
+    const int p = ks / 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {-1, -1, -1, -1};
+        for (int r = 0; r < ks; ++r) {
+            const int hi = h + r - p;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int q = 0; q < ks; ++q) {
+                const int wi = w + q - p;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = ld4(x + ((b * H + hi) * W + wi) * ldx + c);
+                const int code = r * ks + q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {            // aten max_pool2d: (val > max) || isnan(val); first max wins
+                    if (bi[e] < 0) bi[e] = code;
+                    if (v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = code; }
+                }
+            }
+        }
+        st4(y + pix * ldy + c, best);
+        if (idx) {
+            char4 o;
+            o.x = (signed char)bi[0]; o.y = (signed char)bi[1]; o.z = (signed char)bi[2]; o.w = (signed char)bi[3];
+            *reinterpret_cast<char4*>(idx + pix * (long long)(C4 * 4) + c) = o;
+        }
+    }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(PW_THREADS) void maxpool_bwd_kernel(const float* __restrict__ dy, long long lddy,
+                                                                 const signed char* __restrict__ idx,
+                                                                 float* __restrict__ dx, long long lddx,
+                                                                 int B, int H, int W, int C4, int ks) {
+    const long long total = (long long)B * H * W * C4;
+    const int p = ks / 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        f32x4 s = {0, 0, 0, 0};
+        for (int r = 0; r < ks; ++r) {
+            const int ho = h - r + p;                      // output whose window offset r lands on h
+            if ((unsigned)ho >= (unsigned)H) continue;
+            for (int q = 0; q < ks; ++q) {
+                const int wo = w - q + p;
+                if ((unsigned)wo >= (unsigned)W) continue;
+                const long long op = (b * H + ho) * W + wo;
+                const char4 id = *reinterpret_cast<const char4*>(idx + op * (long long)(C4 * 4) + c);
+                const int code = r * ks + q;
+                if (id.x == code || id.y == code || id.z == code || id.w == code) {
+                    const f32x4 g = ld4(dy + op * lddy + c);
+                    if (id.x == code) s[0] += g[0];
+                    if (id.y == code) s[1] += g[1];
+                    if (id.z == code) s[2] += g[2];
+                    if (id.w == code) s[3] += g[3];
+                }
+            }
+        }
+        float* o = dx + pix * lddx + c;
+        if (ACC) s += ld4(o);
+        st4(o, s);
+    }
+}
+
+// ---------------------------------------------------------------- nearest x2 upsample
+__global__ __launch_bounds__(PW_THREADS) void upsample2x_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                                    float* __restrict__ y, long long ldy,
+                                                                    int B, int H, int W, int C4) {
+    const int H2 = 2 * H, W2 = 2 * W;
+    const long long total = (long long)B * H2 * W2 * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int w = (int)(pix % W2);
+        const int h = (int)((pix / W2) % H2);
+        const long long b = pix / ((long long)W2 * H2);
+        st4(y + pix * ldy + c, ld4(x + ((b * H + (h >> 1)) * W + (w >> 1)) * ldx + c));
+    }
+}
+__global__ __launch_bounds__(PW_THREADS) void upsample2x_bwd_kernel(const float* __restrict__ dy, long long lddy,
+                                                                    float* __restrict__ dx, long long lddx,
+                                                                    int B, int H, int W, int C4) {
+    const int W2 = 2 * W, H2 = 2 * H;
+    const long long total = (long long)B * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        const long long o = (b * H2 + 2 * h) * W2 + 2 * w;
+        // same order as the reference's autograd would sum is irrelevant: 4 terms, fixed order here
+        f32x4 s = ld4(dy + o * lddy + c) + ld4(dy + (o + 1) * lddy + c);
+        s += ld4(dy + (o + W2) * lddy + c) + ld4(dy + (o + W2 + 1) * lddy + c);
+        st4(dx + pix * lddx + c, s);
+    }
+}
+
+inline int grid_for(long long total, int cap = 256 * 16) {
+    long long b = (total + PW_THREADS - 1) / PW_THREADS;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+inline bool vec_ok(const void* p, long long ld, int C) {
+    return p && (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (C & 3) == 0 && ld >= C && C > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t y4_bn_workspace(int C) { return (size_t)2 * C * sizeof(double); }
+
+int y4_bn_stats_f32(const float* y, int ldy, long long M, int C, float* mean, float* invstd,
+                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!y || !mean || !invstd || !workspace) return Y4_ERR_NULL;
+    if (!vec_ok(y, ldy, C) || M <= 0) return Y4_ERR_SHAPE;
+    if (workspace_bytes < y4_bn_workspace(C)) return Y4_ERR_WORKSPACE;
+    hipStream_t st = y4_stream(stream);
+    double* acc = static_cast<double*>(workspace);
+    if (hipMemsetAsync(acc, 0, y4_bn_workspace(C), st) != hipSuccess) return Y4_ERR_LAUNCH;
+    const RowMap rm = row_map(C);
+    const long long rows_per_block = (long long)rm.rpb * STAT_ROWS_PER_THREAD;
+    const long long blocks = (M + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, y, (long long)ldy, M, C,
+                       rm.tpr, rm.rpb, acc);
+    Y4_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, M, C, eps, momentum, mean,
+                       invstd, running_mean, running_var, num_batches_tracked);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int act,
+                      const float* residual, int ldr, float* z, int ldz,
+                      long long M, int C, void* stream) {
+    if (!y || !mean || !invstd || !gamma || !beta || !z) return Y4_ERR_NULL;
+    if (!vec_ok(y, ldy, C) || !vec_ok(z, ldz, C) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
+        return Y4_ERR_SHAPE;
+    const RowMap rm = row_map(C);
+    long long blocks = (M + rm.rpb - 1) / rm.rpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
+                       (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
+                       M, C, rm.tpr, rm.rpb);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
+                      const float* mean, const float* invstd, const float* gamma, const float* beta,
+                      int act, float* dy, int lddy, float* dgamma, float* dbeta,
+                      long long M, int C, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
+    if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
+    if (workspace_bytes < y4_bn_workspace(C)) return Y4_ERR_WORKSPACE;
+    hipStream_t st = y4_stream(stream);
+    double* acc = static_cast<double*>(workspace);
+    if (hipMemsetAsync(acc, 0, y4_bn_workspace(C), st) != hipSuccess) return Y4_ERR_LAUNCH;
+    const RowMap rm = row_map(C);
+    const long long rows_per_block = (long long)rm.rpb * STAT_ROWS_PER_THREAD;
+    const long long rblocks = (M + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((unsigned)rblocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz,
+                       y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, acc);
+    Y4_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, C, dgamma, dbeta);
+    Y4_CHECK_LAUNCH();
+    long long blocks = (M + rm.rpb - 1) / rm.rpb;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
+                       (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_bias_grad_f32(const float* dy, int lddy, long long M, int C, float* dbias,
+                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !dbias || !workspace) return Y4_ERR_NULL;
+    if (M <= 0 || C <= 0 || lddy < C) return Y4_ERR_SHAPE;
+    if (workspace_bytes < (size_t)C * sizeof(double)) return Y4_ERR_WORKSPACE;
+    hipStream_t st = y4_stream(stream);
+    double* acc = static_cast<double*>(workspace);
+    if (hipMemsetAsync(acc, 0, (size_t)C * sizeof(double), st) != hipSuccess) return Y4_ERR_LAUNCH;
+    const long long rb = (M + 255) / 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)rb, (C + 255) / 256), dim3(256), 0, st, dy, (long long)lddy, M, C, acc);
+    Y4_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, C, dbias);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return Y4_ERR_NULL;
+    if (C <= 0) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, y4_stream(stream), gamma, beta,
+                       running_mean, running_var, eps, scale, shift, C);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_copy_channels_f32(const float* src, int lds, float* dst, int ldd, long long M, int C, void* stream) {
+    if (!vec_ok(src, lds, C) || !vec_ok(dst, ldd, C) || M <= 0) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(PW_THREADS), 0, y4_stream(stream),
+                       src, (long long)lds, dst, (long long)ldd, M, C / 4);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_add_f32(const float* a, int lda, const float* b, int ldb, float* out, int ldo,
+               long long M, int C, void* stream) {
+    if (!vec_ok(a, lda, C) || !vec_ok(b, ldb, C) || !vec_ok(out, ldo, C) || M <= 0) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(PW_THREADS), 0, y4_stream(stream),
+                       a, (long long)lda, b, (long long)ldb, out, (long long)ldo, M, C / 4);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_maxpool_s1_fwd_f32(const float* x, int ldx, float* y, int ldy, signed char* idx,
+                          int B, int H, int W, int C, int ksize, void* stream) {
+    if (!vec_ok(x, ldx, C) || !vec_ok(y, ldy, C) || B <= 0 || H <= 0 || W <= 0) return Y4_ERR_SHAPE;
+    if (ksize < 1 || (ksize & 1) == 0 || ksize > 11) return Y4_ERR_SHAPE;     // idx code r*k+q must fit int8
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(PW_THREADS), 0,
+                       y4_stream(stream), x, (long long)ldx, y, (long long)ldy, idx, B, H, W, C / 4, ksize);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_maxpool_s1_bwd_f32(const float* dy, int lddy, const signed char* idx, float* dx, int lddx,
+                          int accumulate, int B, int H, int W, int C, int ksize, void* stream) {
+    if (!idx) return Y4_ERR_NULL;
+    if (!vec_ok(dy, lddy, C) || !vec_ok(dx, lddx, C) || B <= 0 || H <= 0 || W <= 0) return Y4_ERR_SHAPE;
+    if (ksize < 1 || (ksize & 1) == 0 || ksize > 11) return Y4_ERR_SHAPE;
+    const int grid = grid_for((long long)B * H * W * (C / 4));
+    if (accumulate)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<true>, dim3(grid), dim3(PW_THREADS), 0, y4_stream(stream), dy,
+                           (long long)lddy, idx, dx, (long long)lddx, B, H, W, C / 4, ksize);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<false>, dim3(grid), dim3(PW_THREADS), 0, y4_stream(stream), dy,
+                           (long long)lddy, idx, dx, (long long)lddx, B, H, W, C / 4, ksize);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_upsample2x_fwd_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int C, void* stream) {
+    if (!vec_ok(x, ldx, C) || !vec_ok(y, ldy, C) || B <= 0 || H <= 0 || W <= 0) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long long)B * 4 * H * W * (C / 4))), dim3(PW_THREADS), 0,
+                       y4_stream(stream), x, (long long)ldx, y, (long long)ldy, B, H, W, C / 4);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_upsample2x_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int B, int H, int W, int C, void* stream) {
+    if (!vec_ok(dy, lddy, C) || !vec_ok(dx, lddx, C) || B <= 0 || H <= 0 || W <= 0) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(PW_THREADS), 0,
+                       y4_stream(stream), dy, (long long)lddy, dx, (long long)lddx, B, H, W, C / 4);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+# -*- coding: utf-8 -*-
+"""CSPDarknet53 building blocks behind the reference's module API
+(darknet/darknet.py:14-138 of zjykzj/YOLOv4), executed by libyolov4_amd.so.
+
+`conv` / `norm` / `act` sub-modules exist only as parameter containers with the
+reference's attribute names (so state_dict keys and shapes are identical); their
+own forward() is never called -- ConvBNAct.forward issues one fused library
+sequence instead: implicit-GEMM conv (MFMA) -> batch statistics -> normalise +
+activation (+ ResBlock skip), or in eval mode a single conv kernel with the
+folded BatchNorm, activation and skip in its epilogue.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+
+
+class Mish(nn.Module):
+    """x * tanh(softplus(x)); marker module -- the arithmetic is fused into the library kernels."""
+
+    def forward(self, x):
+        raise ops.Y4Error('Mish is fused into ConvBNAct on this path and has no standalone kernel')
+
+
+_ACT_MODULES = {
+    'relu': lambda: nn.ReLU(inplace=True),
+    'leaky_relu': lambda: nn.LeakyReLU(negative_slope=0.1, inplace=True),
+    'mish': Mish,
+    'linear': nn.Identity,
+}
+
+
+class ConvBNAct(nn.Module):
+
+    def __init__(self, in_ch: int, out_ch: int, kernel_size: int, stride: int, bias=False, bn=True, act='leaky_relu'):
+        super().__init__()
+        if act not in _ACT_MODULES:
+            raise ValueError(f"{act} does not support.")
+        pad = (kernel_size - 1) // 2
+        self.conv = nn.Conv2d(in_ch, out_ch, (kernel_size, kernel_size), (stride, stride), padding=pad, bias=bias)
+        # KRSC in memory, OIHW in the state_dict
+        self.conv.weight.data = self.conv.weight.data.contiguous(memory_format=torch.channels_last)
+        self.norm = nn.BatchNorm2d(out_ch) if bn else nn.Identity()
+        self.act = _ACT_MODULES[act]()
+        self.act_name = act
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.has_bn = bool(bn)
+
+    def forward(self, x, residual=None):
+        n = self.norm
+        cfg = {'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
+               'training': self.training}
+        if self.has_bn:
+            use_batch_stats = self.training or n.running_mean is None
+            cfg['training'] = use_batch_stats
+            cfg['eps'] = n.eps
+            # nn.BatchNorm2d: momentum None = cumulative average
+            cfg['momentum'] = n.momentum if n.momentum is not None else 1.0 / float(int(n.num_batches_tracked) + 1)
+            track = self.training and n.track_running_stats
+            cfg['running_mean'] = n.running_mean if (track or not use_batch_stats) else None
+            cfg['running_var'] = n.running_var if (track or not use_batch_stats) else None
+            cfg['nbt'] = n.num_batches_tracked if track else None
+            gamma, beta = n.weight, n.bias
+        else:
+            gamma = beta = None
+        w = self.conv.weight
+        if w.dim() == 4 and not w.is_contiguous(memory_format=torch.channels_last):
+            # e.g. after load_state_dict into a freshly built module on another device
+            self.conv.weight.data = w.data.contiguous(memory_format=torch.channels_last)
+            w = self.conv.weight
+        return ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
+
+
+class ResBlock(nn.Module):
+
+    def __init__(self, ch, num_blocks=1, shortcut=True, act="mish"):
+        super().__init__()
+        self.shortcut = shortcut
+        self.module_list = nn.ModuleList(
+            nn.Sequential(ConvBNAct(ch, ch, 1, 1, act=act), ConvBNAct(ch, ch, 3, 1, act=act))
+            for _ in range(num_blocks))
+
+    def forward(self, x):
+        for pair in self.module_list:
+            if self.shortcut:
+                xa, xb = ops.fork(x)
+                x = pair[1](pair[0](xa), residual=xb)      # skip fused into the 3x3's epilogue
+            else:
+                x = pair[1](pair[0](x))
+        return x
+
+
+class CSPDownSample0(nn.Module):
+
+    def __init__(self, in_ch=32, out_ch=64, kernel_size=3, stride=2, act='mish'):
+        super().__init__()
+        self.base = ConvBNAct(in_ch, out_ch, kernel_size, stride, act=act)
+        self.part1 = ConvBNAct(out_ch, out_ch, 1, 1, act=act)
+        self.part2_1_1 = ConvBNAct(out_ch, out_ch, 1, 1, act=act)
+        self.part2_1_2 = nn.Sequential(ConvBNAct(out_ch, out_ch // 2, 1, 1, act=act),
+                                       ConvBNAct(out_ch // 2, out_ch, 3, 1, act=act))
+        self.part2_2 = ConvBNAct(out_ch, out_ch, 1, 1, act=act)
+        self.transition = ConvBNAct(out_ch * 2, out_ch, 1, 1, act=act)
+
+    def forward(self, x):
+        xa, xb = ops.fork(self.base(x))
+        x1 = self.part1(xa)
+        ta, tb = ops.fork(self.part2_1_1(xb))
+        x2 = self.part2_1_2[1](self.part2_1_2[0](ta), residual=tb)
+        x2 = self.part2_2(x2)
+        return self.transition(ops.cat([x2, x1]))
+
+
+class CSPDownSample(nn.Module):
+
+    def __init__(self, in_ch=64, out_ch=128, kernel_size=3, stride=2, num_blocks=1, shortcut=True, act='mish'):
+        super().__init__()
+        self.base = ConvBNAct(in_ch, out_ch, kernel_size, stride, act=act)
+        self.part1 = ConvBNAct(out_ch, out_ch // 2, 1, 1, act=act)
+        self.part2 = nn.Sequential(ConvBNAct(out_ch, out_ch // 2, 1, 1, act=act),
+                                   ResBlock(out_ch // 2, num_blocks=num_blocks, shortcut=shortcut, act=act),
+                                   ConvBNAct(out_ch // 2, out_ch // 2, 1, 1, act=act))
+        self.transition = ConvBNAct(out_ch, out_ch, 1, 1, act=act)
+
+    def forward(self, x):
+        xa, xb = ops.fork(self.base(x))
+        x1 = self.part1(xa)
+        x2 = self.part2(xb)
+        return self.transition(ops.cat([x2, x1]))

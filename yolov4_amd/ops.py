@@ -1,0 +1,580 @@
+# -*- coding: utf-8 -*-
+"""Host-side operators over libyolov4_amd.so.
+
+PyTorch is used here for device memory (caching allocator), streams and the
+autograd tape only; every arithmetic kernel on the path is a HIP kernel of the
+library, reached through the C ABI (yolov4_amd/_lib.py).
+
+Tensor convention: activations are logical NCHW torch tensors whose memory is
+NHWC (torch.channels_last), possibly a channel slice of a wider NHWC buffer
+(pixel pitch `ld` > C).  Conv weights are logical OIHW (the reference's
+state_dict layout, darknet/darknet.py:31-36) stored channels_last == KRSC.
+"""
+import ctypes
+
+import torch
+
+from ._lib import ACT_IDS, Y4Error, check, float_array, int_array, lib
+
+CL = torch.channels_last
+
+
+# ------------------------------------------------------------------ plumbing
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise Y4Error(f'{what}: tensor is on {t.device}; the yolov4_amd hot path runs on an MI355X only '
+                      '(no CPU fallback)')
+    if t.dtype != torch.float32:
+        raise Y4Error(f'{what}: expected float32, got {t.dtype}')
+
+
+def nhwc_pitch(t):
+    """Pixel pitch of a logical-NCHW tensor stored NHWC (possibly a channel
+    slice), or None if the memory is not in that form."""
+    if t.dim() != 4:
+        return None
+    B, C, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if C > 1 and sc != 1:
+        return None
+    ld = sw if W > 1 else (sh if H > 1 else (sb if B > 1 else C))
+    if ld < C:
+        return None
+    if W > 1 and sw != ld:
+        return None
+    if H > 1 and sh != W * ld:
+        return None
+    if B > 1 and sb != H * W * ld:
+        return None
+    return ld
+
+
+def empty_nhwc(B, C, H, W, device, pad_to=1):
+    """[B,C,H,W] logical view over an NHWC buffer whose pitch is C rounded up to pad_to."""
+    Cp = (C + pad_to - 1) // pad_to * pad_to
+    buf = torch.empty((B, Cp, H, W), device=device, dtype=torch.float32, memory_format=CL)
+    return buf if Cp == C else buf[:, :C]
+
+
+def as_nhwc(t, need_vec4=True, min_pitch=0):
+    """Return (tensor, ld) with NHWC memory, 16-B aligned base, ld % 4 == 0 and
+    ld >= min_pitch; repacks (one torch copy, boundary plumbing) only when the
+    caller handed a tensor in another layout."""
+    ld = nhwc_pitch(t)
+    ok = ld is not None and (not need_vec4 or (ld % 4 == 0 and t.data_ptr() % 16 == 0)) and ld >= min_pitch
+    if ok:
+        return t, ld
+    B, C, H, W = t.shape
+    pad = 1
+    if need_vec4:
+        pad = 4
+    if min_pitch > C:
+        pad = max(pad, 32)
+    out = empty_nhwc(B, C, H, W, t.device, pad_to=pad)
+    out.copy_(t)
+    return out, nhwc_pitch(out)
+
+
+def krsc(w):
+    """Conv weight [Cout,Cin,k,k] as a KRSC device pointer holder (channels_last memory)."""
+    if w.dim() != 4:
+        raise Y4Error('conv weight must be 4-D')
+    Co, Ci, kh, kw = w.shape
+    exp = (kh * kw * Ci, 1, kw * Ci, Ci)
+    st = w.stride()
+    same = all(w.shape[i] == 1 or st[i] == exp[i] for i in range(4))
+    return w if same else w.contiguous(memory_format=CL)
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
+
+
+def conv_out_hw(H, W, k, s):
+    p = (k - 1) // 2
+    return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+
+
+# ------------------------------------------------------------------ raw op wrappers (no autograd)
+def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1):
+    L = lib()
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = conv_out_hw(H, W, k, s)
+    if out is None:
+        out = empty_nhwc(B, Cout, Ho, Wo, x.device, pad_to=out_pad)
+    ldy = nhwc_pitch(out)
+    w = krsc(w)
+    if Cin == 3:
+        if k != 3 or s != 1 or residual is not None:
+            raise Y4Error('Cin=3 is supported for the 3x3/s1 stem only')
+        sb, sc, sh, sw = x.stride()
+        check(L.y4_conv2d_stem_fwd_f32(_ptr(x), sb, sc, sh, sw, _ptr(w), _ptr(out), ldy, B, H, W, Cout,
+                                       _ptr(scale), _ptr(shift), ACT_IDS[act], _stream()), 'conv2d_stem_fwd')
+        return out
+    x, ldx = as_nhwc(x)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = as_nhwc(residual, need_vec4=False)
+    check(L.y4_conv2d_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, B, H, W, Cin, Cout, k, s,
+                              _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _stream()), 'conv2d_fwd')
+    return out
+
+
+def conv_dgrad_raw(dy, w, x_shape, k, s):
+    L = lib()
+    B, Cin, H, W = x_shape
+    Cout = w.shape[0]
+    cpad = (Cout + 31) // 32 * 32
+    dy, lddy = as_nhwc(dy, min_pitch=cpad)
+    dx = empty_nhwc(B, Cin, H, W, dy.device)
+    nbytes = L.y4_conv2d_dgrad_workspace(Cin, Cout, k)
+    ws = _ws(nbytes, dy.device)
+    check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
+                                _ptr(ws), nbytes, _stream()), 'conv2d_dgrad')
+    return dx
+
+
+def conv_wgrad_raw(x, dy, w_shape, k, s):
+    L = lib()
+    B, Cin, H, W = x.shape
+    Cout = w_shape[0]
+    dw = torch.empty(w_shape, device=dy.device, dtype=torch.float32).contiguous(memory_format=CL)
+    dw = krsc(dw)
+    if Cin == 3:
+        dy, lddy = as_nhwc(dy, need_vec4=False)
+        nbytes = L.y4_conv2d_stem_wgrad_workspace(B, H, W, Cout)
+        ws = _ws(nbytes, dy.device)
+        sb, sc, sh, sw = x.stride()
+        check(L.y4_conv2d_stem_wgrad_f32(_ptr(x), sb, sc, sh, sw, _ptr(dy), lddy, _ptr(dw), B, H, W, Cout,
+                                         _ptr(ws), nbytes, _stream()), 'conv2d_stem_wgrad')
+        return dw
+    x, ldx = as_nhwc(x)
+    dy, lddy = as_nhwc(dy, min_pitch=(Cout + 3) // 4 * 4)
+    nbytes = L.y4_conv2d_wgrad_workspace(B, H, W, Cin, Cout, k, s)
+    ws = _ws(nbytes, dy.device)
+    check(L.y4_conv2d_wgrad_f32(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, H, W, Cin, Cout, k, s,
+                                _ptr(ws), nbytes, _stream()), 'conv2d_wgrad')
+    return dw
+
+
+def bn_stats_raw(y, running_mean, running_var, nbt, momentum, eps):
+    L = lib()
+    B, C, H, W = y.shape
+    y, ld = as_nhwc(y)
+    mean = torch.empty(C, device=y.device, dtype=torch.float32)
+    invstd = torch.empty(C, device=y.device, dtype=torch.float32)
+    nbytes = L.y4_bn_workspace(C)
+    ws = _ws(nbytes, y.device)
+    check(L.y4_bn_stats_f32(_ptr(y), ld, B * H * W, C, _ptr(mean), _ptr(invstd), _ptr(running_mean),
+                            _ptr(running_var), _ptr(nbt), float(momentum), float(eps), _ptr(ws), nbytes, _stream()),
+          'bn_stats')
+    return mean, invstd
+
+
+def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None):
+    L = lib()
+    B, C, H, W = y.shape
+    y, ldy = as_nhwc(y)
+    z = empty_nhwc(B, C, H, W, y.device)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = as_nhwc(residual)
+    check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act],
+                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _stream()), 'bn_act_fwd')
+    return z
+
+
+def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act):
+    L = lib()
+    B, C, H, W = y.shape
+    dz, lddz = as_nhwc(dz)
+    y, ldy = as_nhwc(y)
+    dy = empty_nhwc(B, C, H, W, y.device)
+    dgamma = torch.empty(C, device=y.device, dtype=torch.float32)
+    dbeta = torch.empty(C, device=y.device, dtype=torch.float32)
+    nbytes = L.y4_bn_workspace(C)
+    ws = _ws(nbytes, y.device)
+    check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                              ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
+                              _ptr(ws), nbytes, _stream()), 'bn_act_bwd')
+    return dy, dgamma, dbeta
+
+
+def bias_grad_raw(dy):
+    L = lib()
+    B, C, H, W = dy.shape
+    dy, ld = as_nhwc(dy, need_vec4=False)
+    db = torch.empty(C, device=dy.device, dtype=torch.float32)
+    nbytes = C * 8
+    ws = _ws(nbytes, dy.device)
+    check(L.y4_bias_grad_f32(_ptr(dy), ld, B * H * W, C, _ptr(db), _ptr(ws), nbytes, _stream()), 'bias_grad')
+    return db
+
+
+def bn_fold_raw(gamma, beta, rm, rv, eps):
+    L = lib()
+    C = gamma.numel()
+    scale = torch.empty(C, device=gamma.device, dtype=torch.float32)
+    shift = torch.empty(C, device=gamma.device, dtype=torch.float32)
+    check(L.y4_bn_fold_f32(_ptr(gamma), _ptr(beta), _ptr(rm), _ptr(rv), float(eps), _ptr(scale), _ptr(shift), C,
+                           _stream()), 'bn_fold')
+    return scale, shift
+
+
+def add_raw(a, b):
+    L = lib()
+    B, C, H, W = a.shape
+    a, lda = as_nhwc(a)
+    b, ldb = as_nhwc(b)
+    out = empty_nhwc(B, C, H, W, a.device)
+    check(L.y4_add_f32(_ptr(a), lda, _ptr(b), ldb, _ptr(out), nhwc_pitch(out), B * H * W, C, _stream()), 'add')
+    return out
+
+
+def copy_into_raw(src, dst):
+    """dst (a channel slice of an NHWC buffer) <- src"""
+    L = lib()
+    B, C, H, W = src.shape
+    src, lds = as_nhwc(src)
+    ldd = nhwc_pitch(dst)
+    if ldd is None:
+        raise Y4Error('copy_into: destination is not NHWC')
+    check(L.y4_copy_channels_f32(_ptr(src), lds, _ptr(dst), ldd, B * H * W, C, _stream()), 'copy_channels')
+
+
+# ------------------------------------------------------------------ autograd functions
+class ConvBNActFn(torch.autograd.Function):
+    """conv -> BatchNorm -> activation (+ skip), darknet/darknet.py:53-58 (+ :76-80)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, residual, cfg):
+        k, s, act, training, bn = cfg['k'], cfg['s'], cfg['act'], cfg['training'], cfg['bn']
+        _require_gpu(x, 'ConvBNAct input')
+        _require_gpu(weight, 'ConvBNAct weight')
+        ctx.cfg = cfg
+        ctx.x_shape = tuple(x.shape)
+        ctx.has_res = residual is not None
+        if bn and training:
+            if x.shape[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[1] <= 1:
+                raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
+            y = conv_fwd_raw(x, weight, k, s)
+            mean, invstd = bn_stats_raw(y, cfg['running_mean'], cfg['running_var'], cfg['nbt'],
+                                        cfg['momentum'], cfg['eps'])
+            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual)
+            ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
+            ctx.mode = 'bn_train'
+        elif bn:
+            scale, shift = bn_fold_raw(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
+            z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual)
+            ctx.mode = 'bn_eval'
+        else:
+            z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32)
+            if act != 'linear':
+                ctx.mode = 'nobn_act'
+            else:
+                ctx.save_for_backward(x, weight)
+                ctx.mode = 'nobn_linear'
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        cfg = ctx.cfg
+        k, s, act = cfg['k'], cfg['s'], cfg['act']
+        if ctx.mode == 'bn_train':
+            x, weight, y, mean, invstd, gamma, beta = ctx.saved_tensors
+            dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act)
+            dbias = None
+        elif ctx.mode == 'nobn_linear':
+            x, weight = ctx.saved_tensors
+            dy = dz
+            dgamma = dbeta = None
+            dbias = bias_grad_raw(dz) if ctx.needs_input_grad[2] else None
+        else:
+            raise Y4Error(f'backward through ConvBNAct in mode {ctx.mode} is not implemented '
+                          '(the reference trains in train mode only, yolo/engine/build.py:45)')
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.x_shape[1] == 3:
+                raise Y4Error('gradient wrt the network input (stem, Cin=3) is not implemented')
+            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s)
+        dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s) if ctx.needs_input_grad[1] else None
+        dres = dz if ctx.has_res else None
+        return dx, dw, dbias, dgamma, dbeta, dres, None
+
+
+class Fork2Fn(torch.autograd.Function):
+    """A tensor consumed twice; the backward fan-in add is a library kernel
+    instead of autograd's implicit accumulation."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        if g1 is None:
+            return g2
+        if g2 is None:
+            return g1
+        return add_raw(g1, g2)
+
+
+def fork(x):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x
+    return Fork2Fn.apply(x)
+
+
+class CatFn(torch.autograd.Function):
+    """torch.cat(dim=1): copies into channel slices; backward hands out slice views (zero copy)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, _, H, W = xs[0].shape
+        ctx.sizes = [t.shape[1] for t in xs]
+        out = empty_nhwc(B, sum(ctx.sizes), H, W, xs[0].device)
+        o = 0
+        for t in xs:
+            _require_gpu(t, 'cat input')
+            copy_into_raw(t, out[:, o:o + t.shape[1]])
+            o += t.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, o = [], 0
+        for c in ctx.sizes:
+            outs.append(g[:, o:o + c])
+            o += c
+        return tuple(outs)
+
+
+def cat(xs):
+    return CatFn.apply(*xs)
+
+
+class SppPoolCatFn(torch.autograd.Function):
+    """SPPBlock.forward, yolo/model/yolov4.py:66-72: cat([pool5(x), pool9(x), pool5(x), x]) --
+    max_pool3 (13) is constructed but never used."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = lib()
+        _require_gpu(x, 'SPP input')
+        B, C, H, W = x.shape
+        x, ldx = as_nhwc(x)
+        out = empty_nhwc(B, 4 * C, H, W, x.device)
+        ldo = nhwc_pitch(out)
+        need_idx = ctx.needs_input_grad[0]
+        idx5 = torch.empty((B, H, W, C), dtype=torch.int8, device=x.device) if need_idx else None
+        idx9 = torch.empty((B, H, W, C), dtype=torch.int8, device=x.device) if need_idx else None
+        st = _stream()
+        check(L.y4_maxpool_s1_fwd_f32(_ptr(x), ldx, _ptr(out[:, 0:C]), ldo, _ptr(idx5), B, H, W, C, 5, st), 'maxpool5')
+        check(L.y4_maxpool_s1_fwd_f32(_ptr(x), ldx, _ptr(out[:, C:2 * C]), ldo, _ptr(idx9), B, H, W, C, 9, st), 'maxpool9')
+        copy_into_raw(out[:, 0:C], out[:, 2 * C:3 * C])
+        copy_into_raw(x, out[:, 3 * C:4 * C])
+        ctx.idx = (idx5, idx9)
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = lib()
+        B, C, H, W = ctx.shape
+        idx5, idx9 = ctx.idx
+        g, ldg = as_nhwc(g)
+        dx = empty_nhwc(B, C, H, W, g.device)
+        ldx = nhwc_pitch(dx)
+        st = _stream()
+        copy_into_raw(g[:, 3 * C:4 * C], dx)
+        for sl, idx, ks in ((g[:, 0:C], idx5, 5), (g[:, C:2 * C], idx9, 9), (g[:, 2 * C:3 * C], idx5, 5)):
+            check(L.y4_maxpool_s1_bwd_f32(_ptr(sl), ldg, _ptr(idx), _ptr(dx), ldx, 1, B, H, W, C, ks, st), 'maxpool_bwd')
+        return dx
+
+
+class MaxPoolS1Fn(torch.autograd.Function):
+    """nn.MaxPool2d(k, stride=1, padding=k//2)."""
+
+    @staticmethod
+    def forward(ctx, x, ksize):
+        L = lib()
+        _require_gpu(x, 'maxpool input')
+        B, C, H, W = x.shape
+        x, ldx = as_nhwc(x)
+        out = empty_nhwc(B, C, H, W, x.device)
+        idx = torch.empty((B, H, W, C), dtype=torch.int8, device=x.device)
+        check(L.y4_maxpool_s1_fwd_f32(_ptr(x), ldx, _ptr(out), nhwc_pitch(out), _ptr(idx), B, H, W, C, ksize,
+                                      _stream()), 'maxpool')
+        ctx.idx, ctx.ks, ctx.shape = idx, ksize, (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = lib()
+        B, C, H, W = ctx.shape
+        g, ldg = as_nhwc(g)
+        dx = empty_nhwc(B, C, H, W, g.device)
+        check(L.y4_maxpool_s1_bwd_f32(_ptr(g), ldg, _ptr(ctx.idx), _ptr(dx), nhwc_pitch(dx), 0, B, H, W, C, ctx.ks,
+                                      _stream()), 'maxpool_bwd')
+        return dx, None
+
+
+class Upsample2xFn(torch.autograd.Function):
+    """Upsample.forward, yolo/model/yolov4.py:82-90 (nearest, exact x2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = lib()
+        _require_gpu(x, 'upsample input')
+        B, C, H, W = x.shape
+        x, ldx = as_nhwc(x)
+        out = empty_nhwc(B, C, 2 * H, 2 * W, x.device)
+        check(L.y4_upsample2x_fwd_f32(_ptr(x), ldx, _ptr(out), nhwc_pitch(out), B, H, W, C, _stream()), 'upsample')
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = lib()
+        B, C, H, W = ctx.shape
+        g, ldg = as_nhwc(g)
+        dx = empty_nhwc(B, C, H, W, g.device)
+        check(L.y4_upsample2x_bwd_f32(_ptr(g), ldg, _ptr(dx), nhwc_pitch(dx), B, H, W, C, _stream()), 'upsample_bwd')
+        return dx
+
+
+# ------------------------------------------------------------------ YOLO head
+class YoloDecodeTrainFn(torch.autograd.Function):
+    """YOLOLayer.forward train branch, yolo/model/yololayer.py:88-145."""
+
+    @staticmethod
+    def forward(ctx, logits, anchors_wh, n_classes):
+        L = lib()
+        _require_gpu(logits, 'YOLOLayer input')
+        B, ch, F, F2 = logits.shape
+        if F != F2:
+            raise Y4Error('YOLOLayer assumes square maps (yololayer.py:94)')
+        n_ch = 5 + n_classes
+        A = ch // n_ch
+        logits, ldl = as_nhwc(logits, need_vec4=False)
+        output = torch.empty((B, A, F, F, n_ch), device=logits.device, dtype=torch.float32)
+        pred = torch.empty((B, A, F, F, 4), device=logits.device, dtype=torch.float32)
+        anc = float_array([v for wh in anchors_wh for v in wh])
+        check(L.y4_yolo_decode_train_f32(_ptr(logits), ldl, _ptr(output), _ptr(pred), B, F, A, n_classes, anc,
+                                         _stream()), 'yolo_decode_train')
+        ctx.save_for_backward(logits)
+        ctx.meta = (B, F, A, n_classes, anchors_wh, ldl)
+        return output, pred
+
+    @staticmethod
+    def backward(ctx, g_output, g_pred):
+        L = lib()
+        (logits,) = ctx.saved_tensors
+        B, F, A, n_classes, anchors_wh, ldl = ctx.meta
+        n_ch = 5 + n_classes
+        if g_output is not None:
+            g_output = g_output.contiguous()
+        if g_pred is not None:
+            g_pred = g_pred.contiguous()
+        cpad = (A * n_ch + 31) // 32 * 32
+        gl = empty_nhwc(B, A * n_ch, F, F, logits.device, pad_to=32)
+        anc = float_array([v for wh in anchors_wh for v in wh])
+        # g_logits pitch = cpad: pad channels are written as zeros by the kernel
+        lg, ldl2 = as_nhwc(logits, need_vec4=False)
+        if ldl2 != cpad:
+            lg = empty_nhwc(B, A * n_ch, F, F, logits.device, pad_to=32)
+            lg.copy_(logits)
+            ldl2 = cpad
+        check(L.y4_yolo_decode_bwd_f32(_ptr(lg), ldl2, _ptr(g_output), _ptr(g_pred), _ptr(gl), B, F, A, n_classes,
+                                       anc, _stream()), 'yolo_decode_bwd')
+        return gl, None, None
+
+
+def yolo_decode_eval(logits, anchors_wh, n_classes, stride, out=None, n_total=None, box_off=0):
+    """YOLOLayer.forward eval branch, yolo/model/yololayer.py:146-166; optionally writes straight
+    into rows [box_off, box_off + A*F*F) of a shared [B, n_total, 5+C] buffer (the torch.cat of
+    yolo/model/yolov4.py:324 without a copy)."""
+    L = lib()
+    _require_gpu(logits, 'YOLOLayer input')
+    B, ch, F, _ = logits.shape
+    n_ch = 5 + n_classes
+    A = ch // n_ch
+    logits, ldl = as_nhwc(logits, need_vec4=False)
+    if out is None:
+        n_total = A * F * F
+        out = torch.empty((B, n_total, n_ch), device=logits.device, dtype=torch.float32)
+        box_off = 0
+    anc = float_array([v for wh in anchors_wh for v in wh])
+    check(L.y4_yolo_decode_eval_f32(_ptr(logits), ldl, _ptr(out), n_total, box_off, B, F, A, n_classes, anc,
+                                    float(stride), _stream()), 'yolo_decode_eval')
+    return out
+
+
+class YoloLossLayerFn(torch.autograd.Function):
+    """YOLOLoss.build_target + loss terms for one layer, yolo/model/yololoss.py:118-371,385-432."""
+
+    @staticmethod
+    def forward(ctx, output, pred, labels, cfg):
+        L = lib()
+        _require_gpu(output, 'YOLOLoss output')
+        B, A, F, _, n_ch = output.shape
+        C = n_ch - 5
+        K = labels.shape[1]
+        if not output.is_contiguous():
+            raise Y4Error('YOLOLoss: `output` must be contiguous [B,A,F,F,5+C]')
+        pred = pred.detach().contiguous()
+        labels = labels.detach().to(device=output.device, dtype=torch.float32).contiguous()
+        nbytes = L.y4_yolo_loss_workspace(B, F, A, K, C)
+        ws = _ws(nbytes, output.device)
+        obj_mask = torch.empty((B, A, F, F), device=output.device, dtype=torch.float32)
+        parts = torch.empty(4, device=output.device, dtype=torch.float64)
+        anchors = float_array([v for wh in cfg['all_anchors'] for v in wh])
+        amask = int_array(cfg['anch_mask'])
+        check(L.y4_yolo_loss_fwd_f32(_ptr(output), _ptr(pred), _ptr(labels), K, B, F, A, C, float(cfg['stride']),
+                                     float(cfg['ignore_thresh']), anchors, len(cfg['all_anchors']), amask,
+                                     _ptr(obj_mask), _ptr(parts), _ptr(ws), nbytes, _stream()), 'yolo_loss_fwd')
+        ctx.meta = (B, F, A, K, C, nbytes)
+        ctx.ws = ws
+        ctx.obj_mask = obj_mask
+        ctx.output = output          # later mutated in place exactly like the reference does
+        ctx.mutate = cfg.get('mutate_output', True)
+        cfg['last'] = dict(obj_mask=obj_mask, parts=parts, ws=ws, nbytes=nbytes, dims=(B, F, A, K, C))
+        loss = parts.sum().to(torch.float32)
+        if ctx.mutate:
+            # side effect of yololoss.py:402-407 on outputs[*]['output']; done through the raw pointer,
+            # the backward kernel is told that the w/h channels already carry the scale factor
+            check(L.y4_yolo_loss_mask_output_f32(_ptr(output), _ptr(obj_mask), B, F, A, K, C, _ptr(ws), nbytes,
+                                                 _stream()), 'yolo_loss_mask_output')
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        L = lib()
+        B, F, A, K, C, nbytes = ctx.meta
+        g = torch.empty_like(ctx.output)
+        gs = gloss.detach().to(torch.float32).reshape(1).contiguous()
+        check(L.y4_yolo_loss_bwd_f32(_ptr(ctx.output), 1 if ctx.mutate else 0, _ptr(ctx.obj_mask), _ptr(gs), _ptr(g),
+                                     B, F, A, K, C, _ptr(ctx.ws), nbytes, _stream()), 'yolo_loss_bwd')
+        return g, None, None, None
+
+
+def yolo_loss_dense_targets(last):
+    """Materialise target / tgt_mask / tgt_scale (yololoss.py:173-187) from the sparse records."""
+    L = lib()
+    B, F, A, K, C = last['dims']
+    dev = last['obj_mask'].device
+    target = torch.empty((B, A, F, F, 5 + C), device=dev, dtype=torch.float32)
+    tgt_mask = torch.empty((B, A, F, F, 4 + C), device=dev, dtype=torch.float32)
+    tgt_scale = torch.empty((B, A, F, F, 2), device=dev, dtype=torch.float32)
+    check(L.y4_yolo_loss_dense_targets_f32(_ptr(target), _ptr(tgt_mask), _ptr(tgt_scale), B, F, A, K, C,
+                                           _ptr(last['ws']), last['nbytes'], _stream()), 'yolo_loss_dense_targets')
+    return target, tgt_mask, tgt_scale

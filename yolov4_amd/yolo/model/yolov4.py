@@ -1,0 +1,199 @@
+# -*- coding: utf-8 -*-
+"""YOLOv4 detector graph (CSPDarknet53 + SPP + FPN/PAN + 3 heads) behind the
+reference's module API (yolo/model/yolov4.py:26-324); same attribute tree, hence
+the same 648 state_dict keys."""
+import os
+from collections import OrderedDict
+from typing import Dict
+
+import torch
+from torch import nn
+
+from ... import ops
+from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample
+from .yololayer import YOLOLayer
+
+L = 'leaky_relu'
+
+
+def _five(big, small):
+    return nn.Sequential(ConvBNAct(big, small, 1, 1, act=L), ConvBNAct(small, big, 3, 1, act=L),
+                         ConvBNAct(big, small, 1, 1, act=L), ConvBNAct(small, big, 3, 1, act=L),
+                         ConvBNAct(big, small, 1, 1, act=L))
+
+
+class Backbone(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.stem = ConvBNAct(3, 32, 3, 1, act='mish')
+        self.stage1 = CSPDownSample0(32, 64, 3, 2, act='mish')
+        self.stage2 = CSPDownSample(64, 128, 3, 2, num_blocks=2, act='mish')
+        self.stage3 = CSPDownSample(128, 256, 3, 2, num_blocks=8, act='mish')
+        self.stage4 = CSPDownSample(256, 512, 3, 2, num_blocks=8, act='mish')
+        self.stage5 = CSPDownSample(512, 1024, 3, 2, num_blocks=4, act='mish')
+
+    def forward(self, x):
+        x = self.stage2(self.stage1(self.stem(x)))
+        x3 = self.stage3(x)
+        x3a, x3b = ops.fork(x3)
+        x4 = self.stage4(x3a)
+        x4a, x4b = ops.fork(x4)
+        x5 = self.stage5(x4a)
+        return x3b, x4b, x5
+
+
+class SPPBlock(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Sequential(ConvBNAct(1024, 512, 1, 1, act=L), ConvBNAct(512, 1024, 3, 1, act=L),
+                                   ConvBNAct(1024, 512, 1, 1, act=L))
+        # kept for module-tree parity; pooling runs in the fused SPP kernel sequence (5, 9, 5: the
+        # reference never uses max_pool3, yolov4.py:68-70)
+        self.max_pool1 = nn.MaxPool2d(5, 1, 5 // 2)
+        self.max_pool2 = nn.MaxPool2d(9, 1, 9 // 2)
+        self.max_pool3 = nn.MaxPool2d(13, 1, 13 // 2)
+        self.conv2 = ConvBNAct(2048, 512, 1, 1, act=L)
+
+    def forward(self, x):
+        return self.conv2(ops.SppPoolCatFn.apply(self.conv1(x)))
+
+
+class Upsample(nn.Module):
+
+    def forward(self, x, target_size):
+        assert x.dim() == 4
+        if target_size[2] != 2 * x.shape[2] or target_size[3] != 2 * x.shape[3]:
+            raise ops.Y4Error('Upsample: only the exact x2 nearest case of the YOLOv4 neck is implemented')
+        return ops.Upsample2xFn.apply(x)
+
+
+class FPNBlock(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.module1 = nn.Sequential(ConvBNAct(512, 1024, 3, 1, act=L), ConvBNAct(1024, 512, 1, 1, act=L))
+        self.conv3 = ConvBNAct(512, 256, 1, 1)
+        self.upsample1 = Upsample()
+        self.conv4 = ConvBNAct(512, 256, 1, 1, act=L)
+        self.module2 = _five(512, 256)
+        self.conv10 = ConvBNAct(256, 128, 1, 1)
+        self.upsample2 = Upsample()
+        self.conv11 = ConvBNAct(256, 128, 1, 1, act=L)
+        self.module3 = _five(256, 128)
+
+    def forward(self, x3, x4, x5):
+        f3 = self.module1(x5)
+        f3a, f3b = ops.fork(f3)
+        up = self.upsample1(self.conv3(f3a), x4.size())
+        x4 = self.conv4(x4)
+        assert up.shape[2:] == x4.shape[2:]
+        f2 = self.module2(ops.cat([x4, up]))
+        f2a, f2b = ops.fork(f2)
+        up = self.upsample2(self.conv10(f2a), x3.size())
+        x3 = self.conv11(x3)
+        assert up.shape[2:] == x3.shape[2:]
+        f1 = self.module3(ops.cat([x3, up]))
+        return f1, f2b, f3b
+
+
+class PANBlock(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ConvBNAct(128, 256, 3, 2, act=L)
+        self.module1 = _five(512, 256)
+        self.conv7 = ConvBNAct(256, 512, 3, 2, act=L)
+        self.module2 = _five(1024, 512)
+
+    def forward(self, f1, f2, f3):
+        p1, f1b = ops.fork(f1)
+        p2 = self.conv1(f1b)
+        assert p2.shape[2:] == f2.shape[2:]
+        p2 = self.module1(ops.cat([p2, f2]))
+        p2a, p2b = ops.fork(p2)
+        p3 = self.conv7(p2a)
+        assert p3.shape[2:] == f3.shape[2:]
+        p3 = self.module2(ops.cat([p3, f3]))
+        return p1, p2b, p3
+
+
+class Neck(nn.Module):
+
+    def __init__(self):
+        super().__init__()
+        self.spp = SPPBlock()
+        self.fpn = FPNBlock()
+        self.pan = PANBlock()
+
+    def forward(self, x3, x4, x5):
+        return self.pan(*self.fpn(x3, x4, self.spp(x5)))
+
+
+class Head(nn.Module):
+
+    def __init__(self, cfg: Dict, device=None):
+        super().__init__()
+        oc = (4 + 1 + cfg['N_CLASSES']) * 3
+        self.yolo1 = nn.Sequential(ConvBNAct(128, 256, 3, 1, act=L),
+                                   ConvBNAct(256, oc, 3, 1, bias=True, bn=False, act='linear'),
+                                   YOLOLayer(cfg, layer_no=0, device=device))
+        self.yolo2 = nn.Sequential(ConvBNAct(256, 512, 3, 1, act=L),
+                                   ConvBNAct(512, oc, 1, 1, bias=True, bn=False, act='linear'),
+                                   YOLOLayer(cfg, layer_no=1, device=device))
+        self.yolo3 = nn.Sequential(ConvBNAct(512, 1024, 3, 1, act=L),
+                                   ConvBNAct(1024, oc, 1, 1, bias=True, bn=False, act='linear'),
+                                   YOLOLayer(cfg, layer_no=2, device=device))
+
+    def logits(self, p1, p2, p3):
+        assert p1.shape[1] == 128 and p2.shape[1] == 256 and p3.shape[1] == 512
+        return [h[1](h[0](p)) for h, p in ((self.yolo1, p1), (self.yolo2, p2), (self.yolo3, p3))]
+
+    def forward(self, p1, p2, p3):
+        return tuple(h[2](lg) for h, lg in zip((self.yolo1, self.yolo2, self.yolo3), self.logits(p1, p2, p3)))
+
+
+class YOLOv4(nn.Module):
+
+    def __init__(self, cfg: Dict, device=None):
+        super().__init__()
+        assert cfg['TYPE'] == 'YOLOv4'
+        self.backbone = Backbone()
+        self.neck = Neck()
+        self.head = Head(cfg, device=device)
+        self._init(ckpt_path=cfg['BACKBONE_PRETRAINED'])
+
+    def _init(self, ckpt_path=None):
+        # yolov4.py:283-294: Kaiming-normal(fan_out, relu) conv weights, zero conv bias, BN gamma ~ N(0, 0.01)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+        if ckpt_path is not None and os.path.isfile(ckpt_path):
+            # files we did not write are only ever read with weights_only=True
+            ckpt = torch.load(ckpt_path, map_location='cpu', weights_only=True)['state_dict']
+            ckpt = OrderedDict((k.replace("module.backbone.", ""), v) for k, v in ckpt.items() if 'backbone' in k)
+            self.backbone.load_state_dict(ckpt, strict=True)
+
+    def forward(self, x):
+        if x.dtype != torch.float32:
+            x = x.float()              # Transform hands float64 images; apex O0 casts them
+        p1, p2, p3 = self.neck(*self.backbone(x))
+        if self.training:
+            return list(self.head(p1, p2, p3))
+        # eval: the three decodes write into one [B, N, 5+C] buffer (the cat of yolov4.py:324, no copy)
+        logits = self.head.logits(p1, p2, p3)
+        layers = (self.head.yolo1[2], self.head.yolo2[2], self.head.yolo3[2])
+        counts = [ly.n_anchors * lg.shape[2] * lg.shape[3] for ly, lg in zip(layers, logits)]
+        n_total = sum(counts)
+        out = torch.empty((x.shape[0], n_total, 5 + layers[0].n_classes), device=x.device, dtype=torch.float32)
+        off = 0
+        for ly, lg, n in zip(layers, logits, counts):
+            ly.decode_into(lg, out, n_total, off)
+            off += n
+        return out

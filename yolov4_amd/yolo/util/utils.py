@@ -1,0 +1,93 @@
+# -*- coding: utf-8 -*-
+"""Post-processing behind the reference's API (yolo/util/utils.py:32-89, 92-223):
+confidence filter + per-class greedy NMS on the GPU.
+
+Two host round trips per call (candidate counts, survivor counts) replace the
+reference's per-class device->host copies and its Python/numpy loops.  Tie order is
+DEFINED here (score desc, then lower box index first); the reference's comes from an
+unstable numpy argsort and is platform dependent.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from ... import ops
+from ..._lib import check, lib
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise ops.Y4Error('postprocess / nms run on an MI355X only (no CPU fallback)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def nms(bbox, thresh, score=None, limit=None):
+    """bbox [R,4] xyxy, numpy in / numpy int32 indices out, as utils.py:32-89."""
+    bbox = np.asarray(bbox, dtype=np.float32)
+    if len(bbox) == 0:
+        return np.zeros((0,), dtype=np.int32)
+    L = lib()
+    dev = _dev()
+    R = bbox.shape[0]
+    boxes = torch.from_numpy(np.ascontiguousarray(bbox)).to(dev)
+    sc = torch.from_numpy(np.ascontiguousarray(np.asarray(score, dtype=np.float32))).to(dev) if score is not None else None
+    keep = torch.empty(R, dtype=torch.int32, device=dev)
+    nkeep = torch.zeros(1, dtype=torch.int32, device=dev)
+    nbytes = L.y4_nms_workspace(R)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(L.y4_nms_f32(ops._ptr(boxes), ops._ptr(sc), R, float(thresh), int(limit) if limit is not None else 0,
+                       ops._ptr(keep), ops._ptr(nkeep), ops._ptr(ws), nbytes, ops._stream()), 'nms')
+    n = int(nkeep.item())
+    return keep[:n].cpu().numpy().astype(np.int32)
+
+
+def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45):
+    """prediction [B,N,5+C] (xc,yc,w,h,obj,cls...) -> list of [n,7] tensors
+    (x1,y1,x2,y2,obj,cls_conf,cls_id) or None; rows ordered class asc, score desc.
+    Side effect kept from the reference: prediction[:, :, :4] becomes xyxy in place."""
+    L = lib()
+    src = prediction
+    on_host = not prediction.is_cuda
+    if on_host:                       # detect.py:115-118 moves the output to the CPU first
+        prediction = prediction.to(_dev())
+    if prediction.dtype != torch.float32 or not prediction.is_contiguous():
+        raise ops.Y4Error('postprocess expects a contiguous float32 [B,N,5+C] tensor')
+    B, N, n_ch = prediction.shape
+    if n_ch != 5 + num_classes:
+        raise ops.Y4Error('postprocess: last dim must be 5 + num_classes')
+    dev = prediction.device
+    out = [None for _ in range(B)]
+    if N == 0:
+        return out
+    nseg = B * num_classes
+    counts = torch.empty(nseg, dtype=torch.int32, device=dev)
+    st = ops._stream()
+    check(L.y4_post_count_f32(ops._ptr(prediction), B, N, num_classes, float(conf_thre), 1, ops._ptr(counts), st),
+          'post_count')
+    if on_host:
+        src[:, :, :4] = prediction[:, :, :4].cpu()
+    cnt = counts.cpu().numpy().astype(np.int64)                       # host sync 1
+    offs = np.zeros(nseg + 1, dtype=np.int64)
+    np.cumsum(cnt, out=offs[1:])
+    total = int(offs[-1])
+    if total == 0:
+        return out
+    seg_off = torch.from_numpy(offs.astype(np.int32)).to(dev)
+    rows = torch.empty((total, 7), dtype=torch.float32, device=dev)
+    kept = torch.empty(nseg, dtype=torch.int32, device=dev)
+    nbytes = L.y4_post_nms_workspace(total, nseg)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(L.y4_post_nms_f32(ops._ptr(prediction), B, N, num_classes, float(conf_thre), float(nms_thre),
+                            ops._ptr(seg_off), total, ops._ptr(rows), ops._ptr(kept), ops._ptr(ws), nbytes, st),
+          'post_nms')
+    kept_h = kept.cpu().numpy().astype(np.int64)                      # host sync 2
+    for b in range(B):
+        idx = [np.arange(offs[s], offs[s] + kept_h[s]) for s in range(b * num_classes, (b + 1) * num_classes)
+               if kept_h[s] > 0]
+        if not idx:
+            continue
+        sel = torch.from_numpy(np.concatenate(idx)).to(dev)
+        det = rows.index_select(0, sel)
+        out[b] = det.cpu() if on_host else det
+    return out
