@@ -359,8 +359,13 @@ def test_model_eval_golden(dev, golden, hip_model):
     for b in range(2):
         rd = g[f'eval64.det{b}']
         assert det[b].shape == rd.shape
-        assert np.array_equal(det[b][:, 6].cpu().numpy(), rd[:, 6])
-        close(det[b], rd, 1e-4, 1e-4)
+        gd = det[b].cpu().numpy()
+        assert np.array_equal(gd[:, 6], rd[:, 6])                  # same classes, same count per class
+        # scores differ in the 6th digit, so two near-tied boxes of one class may swap places:
+        # compare per class as sets (rows sorted by x1)
+        for c in np.unique(rd[:, 6]):
+            a = gd[gd[:, 6] == c]; r = rd[rd[:, 6] == c]
+            close(a[np.argsort(a[:, 0])], r[np.argsort(r[:, 0])], 1e-4, 1e-4)
     _reset(m, golden)
     recipe.calibrate_bn_(m, recipe.randn((4, 3, 128, 128), 76).to(dev))
     m.eval()
@@ -390,16 +395,49 @@ def test_model_train_step_golden(dev, golden, hip_model):
     assert abs(float(loss) - ref) <= 1e-4 * ref
     loss.backward()
     named = dict(m.named_parameters())
+    # Gradients through 110 layers with B=2 batch statistics are ill-conditioned: the reference's own
+    # fp32 CPU arithmetic is a few percent away from an fp64 evaluation of the same graph (see
+    # test_gradients_within_reference_rounding).  Against the fp32 golden only a loose bound is meaningful.
     for kk, refn in zip([str(q) for q in g['train128.gradnorm_keys']], g['train128.gradnorm']):
         got = float(named[kk].grad.double().norm())
-        assert abs(got - refn) <= 2e-3 * max(refn, 1e-6), (kk, got, refn)
+        assert abs(got - refn) <= 5e-2 * max(refn, 1e-6), (kk, got, refn)
     for k in g.files:
-        if k.startswith('train128.grad.'):
-            close(named[k[14:]].grad, g[k], 1e-3, 1e-3)
-        if k.startswith('train128.gradslice.'):
-            close(named[k[19:]].grad[:8, :16], g[k], 1e-3, 1e-3)
+        if k.startswith('train128.grad.head.'):            # the head is 2 layers from the loss: tight
+            close(named[k[14:]].grad, g[k], 1e-4, 1e-3)
         if k.startswith('train128.after.'):
             close(m.state_dict()[k[15:]], g[k], 1e-5, 1e-4)
+
+
+def test_gradients_within_reference_rounding(dev, golden, hip_model):
+    """Same linear functional of the head logits on three backends: CPU fp64 (truth), CPU fp32 (the
+    reference's arithmetic: torch ATen), HIP fp32.  The HIP path must be as close to the truth as the
+    reference's own fp32 path is (factor 1.5 + 1e-5 floor), parameter by parameter."""
+    m = hip_model
+    _reset(m, golden)
+    S, B = 128, 2
+    sd = NW.empty_state_dict()
+    recipe.fill_state_dict_(sd, int(golden('model')['seed']))
+    x = recipe.randn((B, 3, S, S), 80)
+    G = [recipe.randn((B, 255, S // s, S // s), 900 + i) for i, s in enumerate((8, 16, 32))]
+
+    def run_cpu(dtype):
+        net = NW.RefNet({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}, CFG)
+        lg = net.forward_train(x.to(dtype))
+        torch.autograd.backward(lg, [t.to(dtype) for t in G])
+        return {k: v.grad.double() for k, v in net.p.items() if v.grad is not None}
+
+    g64, g32 = run_cpu(torch.float64), run_cpu(torch.float32)
+    m.train()
+    m.zero_grad(set_to_none=True)
+    lg = m.head.logits(*m.neck(*m.backbone(x.to(dev))))
+    torch.autograd.backward(lg, [t.to(dev) for t in G])
+    e32, eh = [], []
+    for k, p in m.named_parameters():
+        n = float(g64[k].norm())
+        e32.append(float((g32[k] - g64[k]).norm()) / n)
+        eh.append(float((p.grad.double().cpu() - g64[k]).norm()) / n)
+        assert eh[-1] <= 1.5 * e32[-1] + 1e-5, (k, eh[-1], e32[-1])
+    assert np.median(eh) <= 1.2 * np.median(e32) + 1e-6
 
 
 def test_model_matches_oracle_at_608(dev, golden, hip_model):
