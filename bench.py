@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+# -*- coding: utf-8 -*-
+"""Headline benchmark (BASELINE.json): images/sec of one YOLOv4 training step
+(forward + YOLOLoss + backward, no optimizer) at 608x608, batch 64 per GPU,
+synthetic inputs per SURVEY.md §8(d) config 3, exact-fp32 MFMA path.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live: every launch of the
+convolution kernels inside the timed steps is bracketed by HIP events on the
+launch stream; achieved = algorithmic conv FLOPs of those launches / their summed
+durations, for the kernel family with the largest total time.  `cpu_baseline` is
+the oracle (torch CPU fp32 restatement of the reference) running the same step
+on the host cores at a bounded batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FLOP_PER_IMG_608 = 402.63e9       # fwd + dgrad + wgrad conv flops per image @608
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=64, help='images per GPU')
+    ap.add_argument('--size', type=int, default=608)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=1)
+    ap.add_argument('--no-kernel-events', action='store_true')
+    return ap.parse_args()
+
+
+class ConvTimer:
+    """HIP-event brackets around the conv launches (same stream as the kernels)."""
+
+    def __init__(self):
+        self.rec = []
+        self.on = False
+
+    def wrap(self, ops):
+        timer = self
+
+        def bracket(fn, kind, flops_of):
+            def inner(*a, **kw):
+                if not timer.on:
+                    return fn(*a, **kw)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = fn(*a, **kw)
+                e1.record()
+                timer.rec.append((kind, flops_of(*a, **kw), e0, e1))
+                return out
+            return inner
+
+        def f_fwd(x, w, k, s, *a, **kw):
+            B, Cin, H, W = x.shape
+            Ho, Wo = ops.conv_out_hw(H, W, k, s)
+            return 2.0 * B * Ho * Wo * w.shape[0] * Cin * k * k
+
+        def f_dgrad(dy, w, x_shape, k, s):
+            B, Cout, Ho, Wo = dy.shape
+            return 2.0 * B * Ho * Wo * Cout * x_shape[1] * k * k
+
+        def f_wgrad(x, dy, w_shape, k, s):
+            B, Cout, Ho, Wo = dy.shape
+            return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k
+
+        ops.conv_fwd_raw = bracket(ops.conv_fwd_raw, 'conv_fwd', f_fwd)
+        ops.conv_dgrad_raw = bracket(ops.conv_dgrad_raw, 'conv_dgrad', f_dgrad)
+        ops.conv_wgrad_raw = bracket(ops.conv_wgrad_raw, 'conv_wgrad', f_wgrad)
+
+    def summary(self):
+        agg = {}
+        for kind, fl, e0, e1 in self.rec:
+            a = agg.setdefault(kind, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        return {k: {'tflops': v[0] / v[1] / 1e12, 'seconds': v[1], 'launches': v[2], 'flop': v[0]} for k, v in agg.items()}
+
+
+def cpu_baseline(size, batch):
+    import recipe
+    from oracle import network as NW
+    threads = torch.get_num_threads()
+    sd = NW.empty_state_dict()
+    recipe.fill_state_dict_(sd, 1234)
+    net = NW.RefNet(sd, recipe.MODEL_CFG)
+    x = recipe.randn((batch, 3, size, size), 5)
+    labels = recipe.synth_labels(batch, size, 6).numpy()
+    t0 = time.time()
+    net.train_step(x, labels)
+    dt = time.time() - t0
+    return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
+            'sample': f'oracle (torch-CPU fp32 restatement of the reference) train step fwd+loss+bwd, '
+                      f'{batch}x3x{size}x{size}, 1 run, {dt:.1f} s, host cpus {os.cpu_count()}'}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import recipe
+    from yolov4_amd import ops
+    from yolov4_amd.ddp import BucketedDDP
+    from yolov4_amd.yolo.model.yolov4 import YOLOv4
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+
+    timer = ConvTimer()
+    if not args.no_kernel_events:
+        timer.wrap(ops)
+
+    cfg = recipe.MODEL_CFG
+    torch.manual_seed(0)
+    model = YOLOv4(cfg, device=dev)
+    sd = model.state_dict()
+    recipe.fill_state_dict_(sd, 1234)                # identical initial weights on every rank
+    model.load_state_dict(sd)
+    model = model.to(dev).train()
+    ddp = BucketedDDP(model, bucket_mb=25.0)
+    crit = YOLOLoss(cfg, ignore_thresh=0.7, device=dev)
+
+    B, S = args.batch, args.size
+    g = torch.Generator(device='cpu')
+    g.manual_seed(1000 + rank)                       # per-rank shard of the synthetic global batch
+    x = torch.randn((B, 3, S, S), generator=g).to(dev)
+    labels = recipe.synth_labels(B, S, 2000 + rank).to(dev)
+
+    def step():
+        ddp.zero_grad()
+        loss = crit(ddp(x), {'padded_labels': labels})
+        loss.backward()
+        ddp.finish_backward()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    lossv = float(loss.detach())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        flop_img = FLOP_PER_IMG_608 * (S / 608.0) ** 2
+        out = {
+            'metric': 'images/sec fwd+bwd @608x608 bs=64 per GPU (YOLOv4 training step: forward + YOLOLoss + backward)',
+            'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[2]: 1xMI355X training step, {S}x{S} bs={B}/GPU, fwd+bwd+YOLOLoss HIP kernels, '
+                                   f'synthetic targets (SURVEY 8d config 3); random-init weights',
+                       'global_batch': world * B, 'img_size': S, 'parallelism': f'dp{world}',
+                       'loss': lossv, 'conv_tflops_whole_step': value / world * flop_img / 1e12},
+        }
+        if timer.rec:
+            summ = timer.summary()
+            dom = max(summ, key=lambda k: summ[k]['seconds'])
+            kname = {'conv_fwd': 'conv_gather_mfma_f32<..,false> (forward implicit GEMM)',
+                     'conv_dgrad': 'conv_gather_mfma_f32<..,true> (dgrad implicit GEMM, incl. filter transpose)',
+                     'conv_wgrad': 'conv_wgrad_mfma_f32 (+ slab reduce)'}[dom]
+            out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS,
+                               'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'kernel': kname,
+                               'avg_launch_ms': summ[dom]['seconds'] / summ[dom]['launches'] * 1e3,
+                               'launches': summ[dom]['launches'],
+                               'all_conv_kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['seconds'] / args.steps * 1e3, 2)}
+                                                    for k, v in summ.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(S, args.cpu_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
