@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--conv-table', default=None, help='write a per-shape conv timing table to this file')
     return ap.parse_args()
 
 
@@ -66,22 +67,23 @@ class ConvTimer:
                 e0.record()
                 out = fn(*a, **kw)
                 e1.record()
-                timer.rec.append((kind, flops_of(*a, **kw), e0, e1))
+                fl, key = flops_of(*a, **kw)
+                timer.rec.append((kind, fl, e0, e1, key))
                 return out
             return inner
 
         def f_fwd(x, w, k, s, *a, **kw):
             B, Cin, H, W = x.shape
             Ho, Wo = ops.conv_out_hw(H, W, k, s)
-            return 2.0 * B * Ho * Wo * w.shape[0] * Cin * k * k
+            return 2.0 * B * Ho * Wo * w.shape[0] * Cin * k * k, (Cin, w.shape[0], k, s, H)
 
         def f_dgrad(dy, w, x_shape, k, s):
             B, Cout, Ho, Wo = dy.shape
-            return 2.0 * B * Ho * Wo * Cout * x_shape[1] * k * k
+            return 2.0 * B * Ho * Wo * Cout * x_shape[1] * k * k, (x_shape[1], Cout, k, s, x_shape[2])
 
         def f_wgrad(x, dy, w_shape, k, s):
             B, Cout, Ho, Wo = dy.shape
-            return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k
+            return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k, (x.shape[1], Cout, k, s, x.shape[2])
 
         ops.conv_fwd_raw = bracket(ops.conv_fwd_raw, 'conv_fwd', f_fwd)
         ops.conv_dgrad_raw = bracket(ops.conv_dgrad_raw, 'conv_dgrad', f_dgrad)
@@ -89,12 +91,25 @@ class ConvTimer:
 
     def summary(self):
         agg = {}
-        for kind, fl, e0, e1 in self.rec:
+        for kind, fl, e0, e1, _ in self.rec:
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
         return {k: {'tflops': v[0] / v[1] / 1e12, 'seconds': v[1], 'launches': v[2], 'flop': v[0]} for k, v in agg.items()}
+
+    def table(self, steps):
+        agg = {}
+        for kind, fl, e0, e1, key in self.rec:
+            a = agg.setdefault((kind,) + key, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        lines = ['kind        Cin  Cout k s  Hin   n/step  ms/step  TFLOP/s']
+        for (kind, cin, cout, k, s, h), v in rows:
+            lines.append(f'{kind:10s} {cin:5d} {cout:5d} {k} {s} {h:4d} {v[2] / steps:7.1f} {v[1] / steps * 1e3:8.2f} {v[0] / v[1] / 1e12:8.1f}')
+        return '\n'.join(lines)
 
 
 def cpu_baseline(size, batch):
@@ -209,6 +224,9 @@ def main():
                                'launches': summ[dom]['launches'],
                                'all_conv_kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['seconds'] / args.steps * 1e3, 2)}
                                                     for k, v in summ.items()}}
+        if args.conv_table and timer.rec:
+            with open(args.conv_table, 'w') as f:
+                f.write(timer.table(args.steps) + '\n')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, args.cpu_batch)
         print(json.dumps(out))
