@@ -17,19 +17,21 @@ static inline hipStream_t y4_stream(void* s) { return reinterpret_cast<hipStream
 // darknet/darknet.py:14-20: x * tanh(softplus(x)).  With n = e^x:
 // tanh(log(1+n)) = ((1+n)^2-1)/((1+n)^2+1) = n(n+2)/(n(n+2)+2); softplus threshold 20 of
 // torch (returns x above it) coincides with the ratio being exactly 1.0f there.
+// One v_exp_f32 + one v_rcp_f32 (both ~1 ulp): these kernels are HBM-bound only if the
+// activation costs a handful of VALU ops per element.
 __device__ __forceinline__ float y4_mish(float x) {
-    float n = expf(fminf(x, 20.0f));
-    float w = n * (n + 2.0f);
-    return x * (w / (w + 2.0f));
+    const float n = __expf(fminf(x, 20.0f));
+    const float w = n * (n + 2.0f);
+    return x * (w * __frcp_rn(w + 2.0f));
 }
 // d/dx [x * t(x)], t = tanh(softplus(x)):  t + x * (1 - t^2) * sigmoid(x)
 __device__ __forceinline__ float y4_mish_grad(float x) {
-    float n = expf(fminf(x, 20.0f));
-    float w = n * (n + 2.0f);
-    float d = w + 2.0f;
-    float t = w / d;
-    float omt2 = 4.0f * (w + 1.0f) / (d * d);      // 1 - t^2 without cancellation
-    float sg = n / (1.0f + n);
+    const float n = __expf(fminf(x, 20.0f));
+    const float w = n * (n + 2.0f);
+    const float rd = __frcp_rn(w + 2.0f);
+    const float t = w * rd;
+    const float omt2 = 4.0f * (w + 1.0f) * rd * rd;      // 1 - t^2 without cancellation
+    const float sg = n * __frcp_rn(1.0f + n);
     return t + x * omt2 * sg;
 }
 __device__ __forceinline__ float y4_act(float x, int act) {

@@ -30,11 +30,16 @@ struct ConvGeom {
     int K;                        // k*k*Cs
     int act;
     int mtiles, ntiles;
+    // stride-2 dgrad: dest pixels are tiled per parity class (h&1, w&1) so that every row of a
+    // tile sees the SAME set of contributing filter taps (1, 2, 2 or 4 of the 9) and the K loop
+    // visits only those -- no zero-filled MFMAs.  cls_tile0[c] = first M-tile of class c.
+    int cls_tile0[5];
+    int cls_h[2], cls_w[2];       // class extents: (Hd + 1 - ph) / 2, (Wd + 1 - pw) / 2
 };
 
 // TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
 // TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
-//                     valid only when both divisions are exact.
+//                     (stride 2: exact division is guaranteed by the parity-class tiling)
 template <int BM, int BN, int WM, int WN, bool TRANSPOSED>
 __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g) {
     constexpr int PA = BM / 32, PB = BN / 32;         // load passes (32 rows x 8 lanes x 16 B per pass)
@@ -44,6 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                                  // [2][BM][LDS_PITCH]
     float* Bs = smem + 2 * BM * LDS_PITCH;             // [2][BN][LDS_PITCH]
+    int* row_m = reinterpret_cast<int*>(smem + 2 * (BM + BN) * LDS_PITCH);   // [BM] dest pixel of each tile row (-1: none)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -53,7 +59,20 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     const int nwg = g.mtiles * g.ntiles;
     const int lt = y4_xcd_remap(blockIdx.x, nwg);
     const int mt = lt / g.ntiles, nt = lt - mt * g.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int n0 = nt * BN;
+
+    // ---- tap range of this tile (uniform): r in {r0, r0+rstep, ...} < k, same for q
+    int r0 = 0, q0 = 0, tstep = 1;
+    int ph = 0, pw = 0, mt_local = mt;
+    const bool classed = TRANSPOSED && g.stride == 2;
+    if (classed) {
+        int c = 0;
+        while (c < 3 && mt >= g.cls_tile0[c + 1]) ++c;
+        ph = c >> 1; pw = c & 1;
+        mt_local = mt - g.cls_tile0[c];
+        r0 = (ph + g.pad) & 1; q0 = (pw + g.pad) & 1; tstep = 2;
+    }
+    const int nr = (g.k - r0 + tstep - 1) / tstep, nq = (g.k - q0 + tstep - 1) / tstep;
 
     const int lrow = tid >> 3, kc = tid & 7;
 
@@ -63,12 +82,25 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     bool a_ok[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int m = m0 + p * 32 + lrow;
-        a_ok[p] = m < g.M;
-        const int mm = a_ok[p] ? m : 0;
-        const int b = mm / (g.Hd * g.Wd);
-        const int rem = mm - b * (g.Hd * g.Wd);
-        const int hd = rem / g.Wd, wd = rem - hd * g.Wd;
+        const int row = p * 32 + lrow;
+        const int i = mt_local * BM + row;
+        int b, hd, wd;
+        if (!classed) {
+            a_ok[p] = i < g.M;
+            const int ii = a_ok[p] ? i : 0;
+            b = ii / (g.Hd * g.Wd);
+            const int rem = ii - b * (g.Hd * g.Wd);
+            hd = rem / g.Wd; wd = rem - hd * g.Wd;
+        } else {
+            const int hc = g.cls_h[ph], wc = g.cls_w[pw];
+            a_ok[p] = i < g.B * hc * wc;
+            const int ii = a_ok[p] ? i : 0;
+            b = ii / (hc * wc);
+            const int rem = ii - b * (hc * wc);
+            const int hh = rem / wc;
+            hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
+        }
+        if (kc == 0) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
         if (!TRANSPOSED) {
             a_h[p] = hd * g.stride - g.pad;
             a_w[p] = wd * g.stride - g.pad;
@@ -91,9 +123,9 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
 
     f32x4 ra[PA], rb[PB];
     const int CC = g.Cs / BK;
-    int r = 0, q = 0, cc = 0;     // position of the K-tile being LOADED
+    int r = r0, q = q0, cc = 0;   // position of the K-tile being LOADED
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&]() {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             bool ok = a_ok[p];
@@ -104,9 +136,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
                 off = a_base[p] + ((long long)r * g.Ws + q) * g.lds_ + cc * BK;
             } else {
                 const int th = a_h[p] - r, tw = a_w[p] - q;
-                int hi, wi;
-                if (g.stride == 1) { hi = th; wi = tw; }
-                else { ok = ok && ((th | tw) & 1) == 0; hi = th >> 1; wi = tw >> 1; }
+                int hi = th, wi = tw;
+                if (g.stride == 2) { hi = th >> 1; wi = tw >> 1; }     // th, tw even by construction
                 ok = ok && th >= 0 && tw >= 0 && hi < g.Hs && wi < g.Ws;
                 off = a_base[p] + ((long long)hi * g.Ws + wi) * g.lds_ + cc * BK;
             }
@@ -118,11 +149,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
                     if (c + e >= g.Cs_valid) ra[p][e] = 0.f;
             }
         }
+        const long long koff = ((long long)(r * g.k + q) * CC + cc) * BK;
 #pragma unroll
         for (int p = 0; p < PB; ++p)
-            rb[p] = b_ok[p] ? *reinterpret_cast<const f32x4*>(b_ptr[p] + (long long)kt * BK)
-                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (++cc == CC) { cc = 0; if (++q == g.k) { q = 0; ++r; } }
+            rb[p] = b_ok[p] ? *reinterpret_cast<const f32x4*>(b_ptr[p] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } }
     };
     auto store_tile = [&](int buf) {
         float* as = As + buf * BM * LDS_PITCH;
@@ -143,8 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int KT = g.k * g.k * CC;
-    load_tile(0);
+    const int KT = nr * nq * CC;
+    load_tile();
     store_tile(0);
     __syncthreads();
 
@@ -154,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);            // global loads in flight under the MFMAs
+        if (kt + 1 < KT) load_tile();                  // global loads in flight under the MFMAs
         const float* as = As + cur * BM * LDS_PITCH + a_frag;
         const float* bs = Bs + cur * BN * LDS_PITCH + b_frag;
 #pragma unroll
@@ -185,11 +216,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
         const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mbase = m0 + wm * WTM + i * 32 + 4 * fh;
+            const int rbase = wm * WTM + i * 32 + 4 * fh;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = mbase + (e & 3) + 8 * (e >> 2);
-                if (nok && m < g.M) {
+                const int m = row_m[rbase + (e & 3) + 8 * (e >> 2)];
+                if (nok && m >= 0) {
                     float v = acc[i][j][e] * sc + sh;
                     v = y4_act(v, g.act);
                     if (g.res) v += g.res[(long long)m * g.ldr + n];
@@ -217,9 +248,23 @@ __global__ void transpose_filter_kernel(const float* __restrict__ w, float* __re
 template <int BM, int BN, int WM, int WN, bool TR>
 int launch_gather(const ConvGeom& g0, hipStream_t st) {
     ConvGeom g = g0;
-    g.mtiles = (g.M + BM - 1) / BM;
+    if (TR && g.stride == 2) {
+        int t = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int ph = c >> 1, pw = c & 1;
+            g.cls_h[ph] = (g.Hd + 1 - ph) / 2;
+            g.cls_w[pw] = (g.Wd + 1 - pw) / 2;
+            g.cls_tile0[c] = t;
+            const long long n = (long long)g.B * g.cls_h[ph] * g.cls_w[pw];
+            t += (int)((n + BM - 1) / BM);
+        }
+        g.cls_tile0[4] = t;
+        g.mtiles = t;
+    } else {
+        g.mtiles = (g.M + BM - 1) / BM;
+    }
     g.ntiles = (g.N + BN - 1) / BN;
-    const size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float);
+    const size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float) + BM * sizeof(int);
     auto kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -248,29 +293,35 @@ struct WgradGeom {
     int M;          // B*Ho*Wo
     int J;          // k*k*Cin
     int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
+    int tn, tj;     // tile edges chosen by the planner (64 or 128)
 };
 
-constexpr int WG_T = 128;        // tile edge (n and j)
-constexpr int WG_PITCH = WG_T;   // k-major rows of 128 floats; ds_read_b32 across a half-wave is conflict-free
-
+// D[n][j] = sum_p dy[p][n] * xg[p][j].  Block tile TN_ x TJ_ (64 or 128 each), 4 waves as 2x2,
+// K-chunks of 32 pixels, both operands kept pixel-major in LDS exactly as they lie in memory
+// (rows of TN_/TJ_ floats): a half-wave's ds_read_b32 covers 32 consecutive floats, conflict-free.
+template <int TN_, int TJ_>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g) {
+    constexpr int MI = TN_ / 64, MJ = TJ_ / 64;           // 32x32 MFMA tiles per wave
+    constexpr int LPR_A = TN_ / 4, RPP_A = 256 / LPR_A, PA = 32 / RPP_A;
+    constexpr int LPR_B = TJ_ / 4, RPP_B = 256 / LPR_B, PB = 32 / RPP_B;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                           // [2][32][128]  dy tile   (pixel-major)
-    float* Bs = smem + 2 * 32 * WG_PITCH;       // [2][32][128]  x  tile   (pixel-major)
+    float* As = smem;                           // [2][32][TN_]  dy tile   (pixel-major)
+    float* Bs = smem + 2 * 32 * TN_;            // [2][32][TJ_]  x  tile   (pixel-major)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    int bid = blockIdx.x;
-    const int split = bid / (g.ntn * g.ntj);
-    bid -= split * (g.ntn * g.ntj);
+    const int tiles = g.ntn * g.ntj;
+    int bid = y4_xcd_remap(blockIdx.x, tiles * g.splits);   // tiles of one pixel range share an XCD's L2
+    const int split = bid / tiles;
+    bid -= split * tiles;
     const int tn = bid / g.ntj, tj = bid - tn * g.ntj;
-    const int n0 = tn * WG_T, j0 = tj * WG_T;
+    const int n0 = tn * TN_, j0 = tj * TJ_;
 
-    // loader mapping: 8 pixel rows per pass, 32 lanes x 16 B per row; 4 passes
-    const int prow = tid >> 5, c4 = (tid & 31) * 4;
+    const int arow = tid / LPR_A, ac4 = (tid % LPR_A) * 4;
+    const int brow = tid / LPR_B, bc4 = (tid % LPR_B) * 4;
     const int Cout4 = (g.Cout + 3) & ~3;
-    const bool an_ok = (n0 + c4) < Cout4;
-    const int j = j0 + c4;
+    const bool an_ok = (n0 + ac4) < Cout4;
+    const int j = j0 + bc4;
     const bool bj_ok = j < g.J;
     int jr = 0, jq = 0, jc = 0;
     if (bj_ok) { const int tap = j / g.Cin; jc = j - tap * g.Cin; jr = tap / g.k; jq = tap - jr * g.k; }
@@ -279,62 +330,79 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
     int nchunks = (g.M + 31) / 32 - chunk0;
     if (nchunks > g.chunks_per_split) nchunks = g.chunks_per_split;
 
-    f32x4 ra[4], rb[4];
-    auto load_chunk = [&](int ch) {
-        const int pbase = (chunk0 + ch) * 32;
+    // running (b, ho, wo) of this thread's B rows: advanced by 32 pixels per chunk, no divisions
+    int pb_b[PB], pb_h[PB], pb_w[PB];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int pix = pbase + p * 8 + prow;
-            const bool pok = pix < g.M;
-            ra[p] = (pok && an_ok) ? *reinterpret_cast<const f32x4*>(g.dy + (long long)pix * g.lddy + n0 + c4)
-                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-            bool ok = pok && bj_ok;
-            long long off = 0;
-            if (ok) {
-                const int b = pix / (g.Ho * g.Wo);
-                const int rem = pix - b * (g.Ho * g.Wo);
-                const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-                const int hi = ho * g.stride - g.pad + jr, wi = wo * g.stride - g.pad + jq;
-                ok = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-                off = (((long long)b * g.H + hi) * g.W + wi) * g.ldx + jc;
-            }
-            rb[p] = ok ? *reinterpret_cast<const f32x4*>(g.x + off) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < PB; ++p) {
+        const int pix = chunk0 * 32 + p * RPP_B + brow;
+        const int pp = pix < g.M ? pix : 0;
+        pb_b[p] = pp / (g.Ho * g.Wo);
+        const int rem = pp - pb_b[p] * (g.Ho * g.Wo);
+        pb_h[p] = rem / g.Wo;
+        pb_w[p] = rem - pb_h[p] * g.Wo;
+    }
+
+    f32x4 ra[PA], rb[PB];
+    int ld_chunk = 0;
+    auto load_chunk = [&]() {
+        const int pbase = (chunk0 + ld_chunk) * 32;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int pix = pbase + p * RPP_A + arow;
+            ra[p] = (pix < g.M && an_ok) ? *reinterpret_cast<const f32x4*>(g.dy + (long long)pix * g.lddy + n0 + ac4)
+                                         : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int pix = pbase + p * RPP_B + brow;
+            const int hi = pb_h[p] * g.stride - g.pad + jr, wi = pb_w[p] * g.stride - g.pad + jq;
+            const bool ok = pix < g.M && bj_ok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            rb[p] = ok ? *reinterpret_cast<const f32x4*>(g.x + (((long long)pb_b[p] * g.H + hi) * g.W + wi) * g.ldx + jc)
+                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            pb_w[p] += 32;
+            while (pb_w[p] >= g.Wo) { pb_w[p] -= g.Wo; if (++pb_h[p] == g.Ho) { pb_h[p] = 0; ++pb_b[p]; } }
+        }
+        ++ld_chunk;
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<f32x4*>(As + (buf * 32 + p * 8 + prow) * WG_PITCH + c4) = ra[p];
-            *reinterpret_cast<f32x4*>(Bs + (buf * 32 + p * 8 + prow) * WG_PITCH + c4) = rb[p];
-        }
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<f32x4*>(As + (buf * 32 + p * RPP_A + arow) * TN_ + ac4) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<f32x4*>(Bs + (buf * 32 + p * RPP_B + brow) * TJ_ + bc4) = rb[p];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][MJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < MJ; ++jj)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
     if (nchunks > 0) {
-        load_chunk(0);
+        load_chunk();
         store_chunk(0);
         __syncthreads();
         for (int ch = 0; ch < nchunks; ++ch) {
             const int cur = ch & 1;
-            if (ch + 1 < nchunks) load_chunk(ch + 1);
-            const float* as = As + (cur * 32 + fh) * WG_PITCH + wm * 64 + fr;
-            const float* bs = Bs + (cur * 32 + fh) * WG_PITCH + wn * 64 + fr;
+            if (ch + 1 < nchunks) load_chunk();
+            const float* as = As + (cur * 32 + fh) * TN_ + wm * (TN_ / 2) + fr;
+            const float* bs = Bs + (cur * 32 + fh) * TJ_ + wn * (TJ_ / 2) + fr;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float a0 = as[(2 * t) * WG_PITCH], a1 = as[(2 * t) * WG_PITCH + 32];
-                const float b0 = bs[(2 * t) * WG_PITCH], b1 = bs[(2 * t) * WG_PITCH + 32];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                float a[MI], b[MJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = as[(2 * t) * TN_ + i * 32];
+#pragma unroll
+                for (int jj = 0; jj < MJ; ++jj) b[jj] = bs[(2 * t) * TJ_ + jj * 32];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < MJ; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[jj], acc[i][jj], 0, 0, 0);
             }
             if (ch + 1 < nchunks) store_chunk(cur ^ 1);
             __syncthreads();
@@ -343,11 +411,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
     // D[n][j]: row index (n) on the registers, column (j) on the lane
     float* out = g.out + (long long)split * g.Cout * g.J;
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int jcol = j0 + wn * 64 + jj * 32 + fr;
+    for (int jj = 0; jj < MJ; ++jj) {
+        const int jcol = j0 + wn * (TJ_ / 2) + jj * 32 + fr;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int nb = n0 + wm * 64 + i * 32 + 4 * fh;
+        for (int i = 0; i < MI; ++i) {
+            const int nb = n0 + wm * (TN_ / 2) + i * 32 + 4 * fh;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int n = nb + (e & 3) + 8 * (e >> 2);
@@ -374,16 +442,48 @@ void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int stride, Wgrad
     g.Wo = (W + 2 * pad - k) / stride + 1;
     g.M = B * g.Ho * g.Wo;
     g.J = k * k * Cin;
-    g.ntn = (Cout + WG_T - 1) / WG_T;
-    g.ntj = (g.J + WG_T - 1) / WG_T;
+    g.tn = Cout <= 64 ? 64 : 128;
+    g.tj = g.J <= 64 ? 64 : 128;
+    g.ntn = (Cout + g.tn - 1) / g.tn;
+    g.ntj = (g.J + g.tj - 1) / g.tj;
     const int tiles = g.ntn * g.ntj;
     const int chunks = (g.M + 31) / 32;
-    int splits = (1024 + tiles - 1) / tiles;           // aim at ~4 blocks per CU
-    const int max_splits = (chunks + 7) / 8;           // >= 8 chunks (256 pixels) per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    g.chunks_per_split = (chunks + splits - 1) / splits;
+    // resident blocks: LDS = 2*32*(tn+tj)*4 B per block, 160 KiB per CU, <= 8 (wave slots at 4 waves/block)
+    int per_cu = (160 * 1024) / (2 * 32 * (g.tn + g.tj) * 4);
+    if (per_cu > 4) per_cu = 4;
+    if (g.tn + g.tj == 256 && per_cu > 2) per_cu = 2;      // 128x128: 124 VGPRs + 64 KiB
+    const int slots = 256 * per_cu;
+    // choose the split count in [1, chunks/16] that fills whole rounds of `slots` blocks best
+    int max_s = chunks / 16;
+    if (max_s < 1) max_s = 1;
+    if (max_s > 4096) max_s = 4096;
+    int best_s = 1;
+    double best_eff = -1.0;
+    for (int sp = 1; sp <= max_s; ++sp) {
+        const long long blocks = (long long)tiles * sp;
+        const long long rounds = (blocks + slots - 1) / slots;
+        double eff = (double)blocks / (double)(rounds * slots);
+        if (rounds > 6) eff = 1.0;                           // enough rounds: tail is amortised
+        if (eff > best_eff + 0.02) { best_eff = eff; best_s = sp; }
+        if (blocks >= 6ll * slots) break;
+    }
+    g.chunks_per_split = (chunks + best_s - 1) / best_s;
     g.splits = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
+}
+
+template <int TN_, int TJ_>
+int launch_wgrad(const WgradGeom& g, hipStream_t st) {
+    const size_t smem = 2ull * 32 * (TN_ + TJ_) * sizeof(float);
+    auto kern = conv_wgrad_mfma_f32<TN_, TJ_>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
 }
 
 // ------------------------------------------------------------------------------------ stem
@@ -598,16 +698,12 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
     } else {
         g.out = dw;
     }
-    const size_t smem = 2ull * 2 * 32 * WG_PITCH * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_mfma_f32),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(conv_wgrad_mfma_f32, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
-    Y4_CHECK_LAUNCH();
+    int rc;
+    if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128>(g, st);
+    else if (g.tn == 128) rc = launch_wgrad<128, 64>(g, st);
+    else if (g.tj == 128) rc = launch_wgrad<64, 128>(g, st);
+    else rc = launch_wgrad<64, 64>(g, st);
+    if (rc != Y4_OK) return rc;
     if (g.splits > 1) {
         const long long n = (long long)Cout * g.J;
         const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
