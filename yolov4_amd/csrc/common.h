@@ -6,6 +6,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define Y4_CHECK_LAUNCH()                                   \
     do {                                                    \
@@ -58,4 +59,14 @@ __device__ __forceinline__ int y4_xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + (bid >> 3);
+}
+
+// Raw buffer loads (SRD in SGPRs, 32-bit byte offsets): an offset >= num_bytes returns zeros in
+// hardware, which replaces both the branch around a masked load and the select on its result.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t y4_make_rsrc(const void* base, unsigned num_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)num_bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 y4_buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0);
+    return __builtin_bit_cast(f32x4, v);
 }

@@ -35,6 +35,8 @@ struct ConvGeom {
     // visits only those -- no zero-filled MFMAs.  cls_tile0[c] = first M-tile of class c.
     int cls_tile0[5];
     int cls_h[2], cls_w[2];       // class extents: (Hd + 1 - ph) / 2, (Wd + 1 - pw) / 2
+    int cls_slot0[5];             // classed launch: per-XCD slot ranges (each XCD gets 1/8 of EVERY class)
+    unsigned src_bytes, wt_bytes; // extents for the buffer descriptors (< 4 GiB, checked on the host)
 };
 
 // TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
@@ -56,30 +58,42 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     const int wm = wave / WN, wn = wave % WN;
 
     // logical tile: N-tiles innermost so the blocks of one XCD chunk reuse the same A panel
-    const int nwg = g.mtiles * g.ntiles;
-    const int lt = y4_xcd_remap(blockIdx.x, nwg);
-    const int mt = lt / g.ntiles, nt = lt - mt * g.ntiles;
-    const int n0 = nt * BN;
-
-    // ---- tap range of this tile (uniform): r in {r0, r0+rstep, ...} < k, same for q
     int r0 = 0, q0 = 0, tstep = 1;
-    int ph = 0, pw = 0, mt_local = mt;
+    int ph = 0, pw = 0, mt_local, nt;
     const bool classed = TRANSPOSED && g.stride == 2;
-    if (classed) {
+    if (!classed) {
+        const int lt = y4_xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+        mt_local = lt / g.ntiles;
+        nt = lt - mt_local * g.ntiles;
+    } else {
+        // Tile cost differs 4:2:2:1 between parity classes, so a contiguous chunk per XCD would
+        // leave XCD 0 with 4x the work of XCD 7.  Every XCD instead walks its own eighth of each
+        // class, heaviest class (4 taps) first: balanced across XCDs, L2-local within a class.
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         int c = 0;
-        while (c < 3 && mt >= g.cls_tile0[c + 1]) ++c;
-        ph = c >> 1; pw = c & 1;
-        mt_local = mt - g.cls_tile0[c];
+        while (c < 3 && slot >= g.cls_slot0[c + 1]) ++c;
+        const int per = g.cls_slot0[c + 1] - g.cls_slot0[c];
+        const int t = xcd * per + (slot - g.cls_slot0[c]);
+        const int tiles_c = (g.cls_tile0[c + 1] - g.cls_tile0[c]) * g.ntiles;
+        if (t >= tiles_c) return;                     // padding slot (whole block, before any barrier)
+        mt_local = t / g.ntiles;
+        nt = t - mt_local * g.ntiles;
+        ph = (3 - c) >> 1; pw = (3 - c) & 1;          // slot range 0 = class (1,1): 4 taps
         r0 = (ph + g.pad) & 1; q0 = (pw + g.pad) & 1; tstep = 2;
     }
+    const int n0 = nt * BN;
     const int nr = (g.k - r0 + tstep - 1) / tstep, nq = (g.k - q0 + tstep - 1) / tstep;
 
     const int lrow = tid >> 3, kc = tid & 7;
 
-    // ---- per-thread A-row bookkeeping (rows are fixed for the whole K loop)
-    long long a_base[PA];
+    // ---- per-thread A-row bookkeeping (rows are fixed for the whole K loop); byte offsets, 32 bit
+    const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, g.src_bytes);
+    const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt, g.wt_bytes);
+    const unsigned OOB = 0xffffffffu;                 // > any num_bytes: the load returns zeros
+    unsigned a_base[PA];
     int a_h[PA], a_w[PA];
     bool a_ok[PA];
+    const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
         const int row = p * 32 + lrow;
@@ -101,69 +115,70 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
             hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
         }
         if (kc == 0) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
+        a_base[p] = (unsigned)b * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
         if (!TRANSPOSED) {
             a_h[p] = hd * g.stride - g.pad;
             a_w[p] = wd * g.stride - g.pad;
-            a_base[p] = (((long long)b * g.Hs + a_h[p]) * g.Ws + a_w[p]) * g.lds_ + kc * 4;
         } else {
             a_h[p] = hd + g.pad;
             a_w[p] = wd + g.pad;
-            a_base[p] = (long long)b * g.Hs * g.Ws * g.lds_ + kc * 4;
         }
     }
-    // ---- per-thread B rows
-    const float* b_ptr[PB];
-    bool b_ok[PB];
+    // ---- per-thread B rows (filter rows n): constant byte offset, the K position is a scalar offset
+    unsigned b_off[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
         const int n = n0 + p * 32 + lrow;
-        b_ok[p] = n < g.N;
-        b_ptr[p] = g.wt + (long long)(b_ok[p] ? n : 0) * g.K + kc * 4;
+        b_off[p] = n < g.N ? (unsigned)n * (unsigned)g.K * 4u + kc * 16u : OOB;
     }
 
     f32x4 ra[PA], rb[PB];
     const int CC = g.Cs / BK;
     int r = r0, q = q0, cc = 0;   // position of the K-tile being LOADED
 
+    // Loads are buffer loads with hardware zero-fill for invalid rows: no branches, no selects, a
+    // handful of VALU ops per row, so the K loop is one basic block the scheduler can interleave.
     auto load_tile = [&]() {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
+            int hi, wi;
             bool ok = a_ok[p];
-            long long off;
             if (!TRANSPOSED) {
-                const int hi = a_h[p] + r, wi = a_w[p] + q;
+                hi = a_h[p] + r; wi = a_w[p] + q;
                 ok = ok && (unsigned)hi < (unsigned)g.Hs && (unsigned)wi < (unsigned)g.Ws;
-                off = a_base[p] + ((long long)r * g.Ws + q) * g.lds_ + cc * BK;
             } else {
                 const int th = a_h[p] - r, tw = a_w[p] - q;
-                int hi = th, wi = tw;
+                hi = th; wi = tw;
                 if (g.stride == 2) { hi = th >> 1; wi = tw >> 1; }     // th, tw even by construction
                 ok = ok && th >= 0 && tw >= 0 && hi < g.Hs && wi < g.Ws;
-                off = a_base[p] + ((long long)hi * g.Ws + wi) * g.lds_ + cc * BK;
             }
-            ra[p] = ok ? *reinterpret_cast<const f32x4*>(g.src + off) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (TRANSPOSED) {     // dy may carry pad channels (Cout = 255 -> 256) with undefined content
-                const int c = cc * BK + kc * 4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (c + e >= g.Cs_valid) ra[p][e] = 0.f;
-            }
+            const unsigned off = a_base[p] + (unsigned)(hi * g.Ws + wi) * pix_bytes;
+            ra[p] = y4_buf_load4(src_rsrc, ok ? off : OOB, (unsigned)(cc * BK) * 4u);
         }
-        const long long koff = ((long long)(r * g.k + q) * CC + cc) * BK;
+        const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 4u);
 #pragma unroll
-        for (int p = 0; p < PB; ++p)
-            rb[p] = b_ok[p] ? *reinterpret_cast<const f32x4*>(b_ptr[p] + koff) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < PB; ++p) rb[p] = y4_buf_load4(wt_rsrc, b_off[p], koff);
         if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } }
     };
+    // pad channels of dy (Cout = 255 -> 256) may hold anything: zero them on the way to LDS
+    int st_cc = 0;
     auto store_tile = [&](int buf) {
         float* as = As + buf * BM * LDS_PITCH;
         float* bs = Bs + buf * BN * LDS_PITCH;
 #pragma unroll
-        for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<f32x4*>(as + (p * 32 + lrow) * LDS_PITCH + kc * 4) = ra[p];
+        for (int p = 0; p < PA; ++p) {
+            f32x4 v = ra[p];
+            if (TRANSPOSED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
+            }
+            *reinterpret_cast<f32x4*>(as + (p * 32 + lrow) * LDS_PITCH + kc * 4) = v;
+        }
 #pragma unroll
         for (int p = 0; p < PB; ++p)
             *reinterpret_cast<f32x4*>(bs + (p * 32 + lrow) * LDS_PITCH + kc * 4) = rb[p];
+        if (++st_cc == CC) st_cc = 0;
     };
 
     f32x16 acc[TM][TN];
@@ -251,7 +266,7 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
     if (TR && g.stride == 2) {
         int t = 0;
         for (int c = 0; c < 4; ++c) {
-            const int ph = c >> 1, pw = c & 1;
+            const int ph = (3 - c) >> 1, pw = (3 - c) & 1;
             g.cls_h[ph] = (g.Hd + 1 - ph) / 2;
             g.cls_w[pw] = (g.Wd + 1 - pw) / 2;
             g.cls_tile0[c] = t;
@@ -261,9 +276,16 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
         g.cls_tile0[4] = t;
         g.mtiles = t;
     } else {
+        g.cls_slot0[0] = 0;
         g.mtiles = (g.M + BM - 1) / BM;
     }
     g.ntiles = (g.N + BN - 1) / BN;
+    {
+        const unsigned long long sb = (unsigned long long)g.B * g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull;
+        const unsigned long long wb = (unsigned long long)g.N * g.K * 4ull;
+        if (sb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;   // 32-bit buffer offsets
+        g.src_bytes = (unsigned)sb; g.wt_bytes = (unsigned)wb;
+    }
     const size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float) + BM * sizeof(int);
     auto kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR>;
     static bool attr_done = false;
@@ -272,14 +294,33 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(256), smem, st, g);
+    int grid = g.mtiles * g.ntiles;
+    if (TR && g.stride == 2) {
+        int sl = 0;
+        for (int c = 0; c < 4; ++c) {
+            g.cls_slot0[c] = sl;
+            sl += ((g.cls_tile0[c + 1] - g.cls_tile0[c]) * g.ntiles + 7) / 8;
+        }
+        g.cls_slot0[4] = sl;
+        grid = sl * 8;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
 
 template <bool TR>
 int dispatch_gather(const ConvGeom& g, hipStream_t st) {
-    if (g.N > 64) return launch_gather<128, 128, 2, 2, TR>(g, st);
+    if (g.N > 64) {
+        // 2 resident blocks per CU (LDS) -> 512 slots.  When 128-row tiles fill the last round badly
+        // (e.g. 724 blocks = 1.41 rounds at 19x19 maps), 64-row tiles (+8 % per-flop cost) win.
+        const long long nt = (g.N + 127) / 128;
+        const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
+        const double c128 = (double)((b128 + 511) / 512) * 128.0;
+        const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.08;
+        if (c64 < c128 && !(TR && g.stride == 2)) return launch_gather<64, 128, 2, 2, TR>(g, st);
+        return launch_gather<128, 128, 2, 2, TR>(g, st);
+    }
     if (g.N > 32) return launch_gather<128, 64, 2, 2, TR>(g, st);
     return launch_gather<128, 32, 4, 1, TR>(g, st);
 }
@@ -294,6 +335,7 @@ struct WgradGeom {
     int J;          // k*k*Cin
     int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
     int tn, tj;     // tile edges chosen by the planner (64 or 128)
+    unsigned x_bytes, dy_bytes;
 };
 
 // D[n][j] = sum_p dy[p][n] * xg[p][j].  Block tile TN_ x TJ_ (64 or 128 each), 4 waves as 2x2,
@@ -331,6 +373,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
     if (nchunks > g.chunks_per_split) nchunks = g.chunks_per_split;
 
     // running (b, ho, wo) of this thread's B rows: advanced by 32 pixels per chunk, no divisions
+    const __amdgpu_buffer_rsrc_t x_rsrc = y4_make_rsrc(g.x, g.x_bytes);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = y4_make_rsrc(g.dy, g.dy_bytes);
+    const unsigned OOB = 0xffffffffu;
     int pb_b[PB], pb_h[PB], pb_w[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
@@ -341,6 +386,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
         pb_h[p] = rem / g.Wo;
         pb_w[p] = rem - pb_h[p] * g.Wo;
     }
+    unsigned a_off[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p)
+        a_off[p] = an_ok ? (unsigned)(chunk0 * 32 + p * RPP_A + arow) * (unsigned)g.lddy * 4u + (unsigned)(n0 + ac4) * 4u : OOB;
+    const unsigned chunk_bytes = 32u * (unsigned)g.lddy * 4u;
+    const unsigned x_pix_bytes = (unsigned)g.ldx * 4u;
 
     f32x4 ra[PA], rb[PB];
     int ld_chunk = 0;
@@ -348,17 +399,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
         const int pbase = (chunk0 + ld_chunk) * 32;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
-            const int pix = pbase + p * RPP_A + arow;
-            ra[p] = (pix < g.M && an_ok) ? *reinterpret_cast<const f32x4*>(g.dy + (long long)pix * g.lddy + n0 + ac4)
-                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = pbase + p * RPP_A + arow < g.M;
+            ra[p] = y4_buf_load4(dy_rsrc, ok ? a_off[p] : OOB, (unsigned)ld_chunk * chunk_bytes);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             const int pix = pbase + p * RPP_B + brow;
             const int hi = pb_h[p] * g.stride - g.pad + jr, wi = pb_w[p] * g.stride - g.pad + jq;
             const bool ok = pix < g.M && bj_ok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-            rb[p] = ok ? *reinterpret_cast<const f32x4*>(g.x + (((long long)pb_b[p] * g.H + hi) * g.W + wi) * g.ldx + jc)
-                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned off = (unsigned)((pb_b[p] * g.H + hi) * g.W + wi) * x_pix_bytes + (unsigned)jc * 4u;
+            rb[p] = y4_buf_load4(x_rsrc, ok ? off : OOB, 0u);
             pb_w[p] += 32;
             while (pb_w[p] >= g.Wo) { pb_w[p] -= g.Wo; if (++pb_h[p] == g.Ho) { pb_h[p] = 0; ++pb_b[p]; } }
         }
@@ -690,6 +740,12 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
     wgrad_plan(B, H, W, Cin, Cout, k, stride, g);
     if ((long long)B * g.Ho * g.Wo >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.x = x; g.dy = dy; g.ldx = ldx; g.lddy = lddy;
+    {
+        const unsigned long long xb = (unsigned long long)B * H * W * (unsigned long long)ldx * 4ull;
+        const unsigned long long db = (unsigned long long)B * g.Ho * g.Wo * (unsigned long long)lddy * 4ull;
+        if (xb >= 0xfffffff0ull || db >= 0xfffffff0ull) return Y4_ERR_SHAPE;   // 32-bit buffer offsets
+        g.x_bytes = (unsigned)xb; g.dy_bytes = (unsigned)db;
+    }
     hipStream_t st = y4_stream(stream);
     if (g.splits > 1) {
         if (!workspace) return Y4_ERR_NULL;
