@@ -64,11 +64,23 @@ int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy
                       const float* scale, const float* shift, int act,
                       const float* residual, int ldr, void* stream);
 
+/* Training-mode variant: raw conv output + BatchNorm batch statistics fused into the epilogue.
+ * partials receives one row [2][Cout] (column sums, sums of squares) per M-tile; *nparts_host
+ * (HOST int64) is set to the number of rows written; feed both to y4_bn_finalize_partials_f32.
+ * partial_bytes >= y4_conv2d_bnstats_workspace(). */
+size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride);
+int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y, int ldy,
+                              int B, int H, int W, int Cin, int Cout, int k, int stride,
+                              float* partials, size_t partial_bytes, long long* nparts_host, void* stream);
+
 /* Stem conv (Cin = 3): x addressed as x[b*sxb + c*sxc + h*sxh + w*sxw] so both the NCHW
- * tensor the reference feeds (yolo/engine/build.py:60) and NHWC work without a copy. */
+ * tensor the reference feeds (yolo/engine/build.py:60) and NHWC work without a copy.
+ * bnstats_partials (nullable): [ceil(B*H*W/256)][2][Cout] column sums of the output, valid when
+ * scale/shift are NULL and act is linear (training-mode BatchNorm statistics). */
 int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
                            const float* w, float* y, int ldy, int B, int H, int W, int Cout,
-                           const float* scale, const float* shift, int act, void* stream);
+                           const float* scale, const float* shift, int act,
+                           float* bnstats_partials, void* stream);
 
 /* dgrad: dx[B,H,W,Cin] = conv_transpose(dy[B,Ho,Wo,Cout], w) -- autograd of nn.Conv2d wrt input.
  * workspace: y4_conv2d_dgrad_workspace() bytes (holds the [Cin][k][k][Cout4] transposed filter). */
@@ -95,19 +107,27 @@ int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long 
  *
  * y4_bn_stats_f32: mean[c], invstd[c] = 1/sqrt(var_biased+eps); running stats updated in place
  *   (running = (1-m)*running + m*batch; running_var uses var*M/(M-1)); *num_batches_tracked += 1.
- *   running_mean/running_var/num_batches_tracked may be NULL.  workspace: 2*C doubles.
+ *   running_mean/running_var/num_batches_tracked may be NULL.  workspace: y4_bn_workspace(M, C)
+ *   bytes (fp64 accumulators + per-block fp32 partial rows; no contended atomics).
+ * y4_bn_finalize_partials_f32: same outputs from the per-M-tile column sums [nparts][2][C] that
+ *   y4_conv2d_fwd_bnstats_f32 / y4_conv2d_stem_fwd_f32 leave behind (statistics fused into the conv
+ *   epilogue: the conv output is not read again).  workspace: 2*C doubles.
  */
-size_t y4_bn_workspace(int C);
+size_t y4_bn_workspace(long long M, int C);
 int y4_bn_stats_f32(const float* y, int ldy, long long M, int C, float* mean, float* invstd,
                     float* running_mean, float* running_var, long long* num_batches_tracked,
                     float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);
+int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long long M, int C,
+                                float* mean, float* invstd, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float momentum, float eps,
+                                void* workspace, size_t workspace_bytes, void* stream);
 /* z = act(gamma*(y-mean)*invstd + beta) + residual   (residual may be NULL) */
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
                       long long M, int C, void* stream);
 /* Backward of the two ops above wrt y, gamma, beta given dz (grad wrt z; the residual branch
- * receives dz itself).  dy may alias dz.  workspace: 2*C doubles. */
+ * receives dz itself).  dy may alias dz.  workspace: y4_bn_workspace(M, C) bytes. */
 int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,

@@ -21,6 +21,7 @@ struct ConvGeom {
     // gathered ("source") tensor and produced ("dest") tensor, both NHWC with pitch
     const float* src; const float* wt; float* dst;
     const float* scale; const float* shift; const float* res;
+    float* stats;                 // forward only, optional: per-M-tile column sums [mtiles][2][N] of the raw output
     long long lds_, ldd, ldr;     // pixel pitches (elements)
     int B, Hs, Ws, Cs;            // source dims (Cs = GEMM-K channels, multiple of 32)
     int Cs_valid;                 // channels >= Cs_valid of the source are treated as zero (pad lanes)
@@ -244,6 +245,39 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
             }
         }
     }
+
+    // ---- BatchNorm batch statistics fused into the epilogue: column sums / sums of squares of this
+    // M-tile (rows beyond M were zero-filled, so they add nothing), one partial row per tile; a tiny
+    // second-stage kernel folds the rows in fp64.  Saves one full read of the conv output.
+    if (!TRANSPOSED && g.stats) {
+        float* red = smem;                                 // [WM][BN][2]; the K loop ended with a barrier
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; cs += v; css += v * v; }
+            cs += __shfl_xor(cs, 32, 64);
+            css += __shfl_xor(css, 32, 64);
+            if (fh == 0) {
+                const int c = wn * WTN + j * 32 + fr;
+                red[(wm * BN + c) * 2 + 0] = cs;
+                red[(wm * BN + c) * 2 + 1] = css;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
+            const int n = n0 + c;
+            if (n < g.N) {
+                g.stats[((long long)mt_local * 2 + 0) * g.N + n] = cs;
+                g.stats[((long long)mt_local * 2 + 1) * g.N + n] = css;
+            }
+        }
+    }
 }
 
 // [Cout][k][k][Cin] -> [Cin][k][k][Cout4] (zero padded to a multiple of 32 output channels)
@@ -310,7 +344,8 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
 }
 
 template <bool TR>
-int dispatch_gather(const ConvGeom& g, hipStream_t st) {
+int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
+    if (bm_used) *bm_used = 128;
     if (g.N > 64) {
         // 2 resident blocks per CU (LDS) -> 512 slots.  When 128-row tiles fill the last round badly
         // (e.g. 724 blocks = 1.41 rounds at 19x19 maps), 64-row tiles (+8 % per-flop cost) win.
@@ -318,7 +353,10 @@ int dispatch_gather(const ConvGeom& g, hipStream_t st) {
         const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
         const double c128 = (double)((b128 + 511) / 512) * 128.0;
         const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.08;
-        if (c64 < c128 && !(TR && g.stride == 2)) return launch_gather<64, 128, 2, 2, TR>(g, st);
+        if (c64 < c128 && !(TR && g.stride == 2)) {
+            if (bm_used) *bm_used = 64;
+            return launch_gather<64, 128, 2, 2, TR>(g, st);
+        }
         return launch_gather<128, 128, 2, 2, TR>(g, st);
     }
     if (g.N > 32) return launch_gather<128, 64, 2, 2, TR>(g, st);
@@ -542,6 +580,7 @@ int launch_wgrad(const WgradGeom& g, hipStream_t st) {
 // addresses); the 128-B pixel rows are transposed through LDS so stores are lane-contiguous.
 struct StemGeom {
     const float* x; const float* w; float* y; const float* scale; const float* shift;
+    float* stats;                 // optional [blocks][2][Cout] column sums of the (raw) output
     long long sxb, sxc, sxh, sxw, ldy;
     int B, H, W, Cout, act;
     long long M;
@@ -549,7 +588,13 @@ struct StemGeom {
 
 __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemGeom g) {
     __shared__ float tile[4][64][33];
+    __shared__ __attribute__((aligned(16))) float wl[27 * 32];          // filter, [tap*3+c][n] (n contiguous)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 27 * 32; i += 256) {
+        const int n = i & 31, kk = i >> 5;
+        wl[i] = n < g.Cout ? g.w[n * 27 + kk] : 0.f;
+    }
+    __syncthreads();
     const long long pix0 = (long long)blockIdx.x * 256 + wave * 64;
     const long long pix = pix0 + lane;
     float acc[32];
@@ -560,6 +605,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemGeom g) {
         const int rem = (int)(pix - (long long)b * g.H * g.W);
         const int h = rem / g.W, w = rem - h * g.W;
         const float* xb = g.x + b * g.sxb;
+        float xv[27];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -567,14 +613,21 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemGeom g) {
                 const int hi = h + r - 1, wi = w + q - 1;
                 const bool ok = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float v = ok ? xb[c * g.sxc + hi * g.sxh + wi * g.sxw] : 0.f;
-                    const float* wp = g.w + (r * 3 + q) * 3 + c;          // w[n][r][q][c], n stride 27
-#pragma unroll
-                    for (int n = 0; n < 32; ++n)
-                        if (n < g.Cout) acc[n] = fmaf(v, wp[n * 27], acc[n]);
-                }
+                for (int c = 0; c < 3; ++c) xv[(r * 3 + q) * 3 + c] = ok ? xb[c * g.sxc + hi * g.sxh + wi * g.sxw] : 0.f;
             }
+        // taps one at a time (sched_barrier keeps the 216 LDS broadcasts from being hoisted into 864 registers)
+#pragma unroll
+        for (int kk = 0; kk < 27; ++kk) {
+            const f32x4* wp = reinterpret_cast<const f32x4*>(wl + kk * 32);
+            const float v = xv[kk];
+#pragma unroll
+            for (int n4 = 0; n4 < 8; ++n4) {
+                const f32x4 wv = wp[n4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[n4 * 4 + e] = fmaf(v, wv[e], acc[n4 * 4 + e]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll
     for (int n = 0; n < 32; ++n) {
@@ -585,7 +638,7 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemGeom g) {
         }
         tile[wave][lane][n] = v;
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
     // 64 pixels x 32 ch: lane -> (pixel = it*2 + lane/32, ch = lane%32): 128-B contiguous per half wave
     const int ch = lane & 31;
     if (ch < g.Cout) {
@@ -594,6 +647,20 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemGeom g) {
             const int pl = it * 2 + (lane >> 5);
             const long long p = pix0 + pl;
             if (p < g.M) g.y[p * g.ldy + ch] = tile[wave][pl][ch];
+        }
+    }
+    if (g.stats) {                                   // uniform branch: column sums of this block's 256 pixels
+        __shared__ float sred[8][32][2];
+        const int grp = tid >> 5;                    // 8 groups of 32 pixels
+        float cs = 0.f, css = 0.f;
+        for (int i = 0; i < 32; ++i) { const float v = tile[grp >> 1][(grp & 1) * 32 + i][ch]; cs += v; css += v * v; }
+        sred[grp][ch][0] = cs; sred[grp][ch][1] = css;
+        __syncthreads();
+        if (tid < 64) {
+            const int c = tid & 31, which = tid >> 5;
+            float t = 0.f;
+            for (int k = 0; k < 8; ++k) t += sred[k][c][which];
+            if (c < g.Cout) g.stats[((long long)blockIdx.x * 2 + which) * g.Cout + c] = t;
         }
     }
 }
@@ -621,20 +688,28 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradGeo
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (long long p = p_begin + fh; p < p_end + fh; p += 2) {      // both halves iterate the same count
+    // running (b, h, w) of this lane's pixel p = p_begin + fh + 2*iter: no divisions in the loop
+    long long p = p_begin + fh;
+    int b = 0, h = 0, w = 0;
+    if (p < g.M) {
+        b = (int)(p / ((long long)g.H * g.W));
+        const int rem = (int)(p - (long long)b * g.H * g.W);
+        h = rem / g.W; w = rem - h * g.W;
+    }
+    const float* dyp = g.dy + p * g.lddy + fr;
+    const long long coff = c * g.sxc;
+    for (; p < p_end + fh; p += 2) {                                 // both halves iterate the same count
         float a = 0.f, bv = 0.f;
         if (p < p_end) {
-            if (nok) a = g.dy[p * g.lddy + fr];
-            if (jok) {
-                const int b = (int)(p / ((long long)g.H * g.W));
-                const int rem = (int)(p - (long long)b * g.H * g.W);
-                const int h = rem / g.W, w = rem - h * g.W;
-                const int hi = h + r, wi = w + q;
-                if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
-                    bv = g.x[b * g.sxb + c * g.sxc + hi * g.sxh + wi * g.sxw];
-            }
+            if (nok) a = *dyp;
+            const int hi = h + r, wi = w + q;
+            if (jok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+                bv = g.x[b * g.sxb + coff + hi * g.sxh + wi * g.sxw];
         }
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        dyp += 2 * g.lddy;
+        w += 2;
+        if (w >= g.W) { w -= g.W; if (++h == g.H) { h = 0; ++b; } }  // W >= 2
     }
     float* out = g.slabs + wave_id * 1024;     // [32 n][32 j]
 #pragma unroll
@@ -644,14 +719,21 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradGeo
     }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                         int nslabs, int Cout) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over Cout*27
-    if (i >= Cout * 27) return;
+// one block per output element: 256 threads fold the per-wave slabs (fp64, fixed order)
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                                int nslabs, int Cout) {
+    __shared__ double red[256];
+    const int i = blockIdx.x;                                 // over Cout*27
     const int n = i / 27, j = i - n * 27;
     double s = 0.0;
-    for (int k = 0; k < nslabs; ++k) s += (double)slabs[(long long)k * 1024 + n * 32 + j];
-    dw[i] = (float)s;
+    for (int k = threadIdx.x; k < nslabs; k += 256) s += (double)slabs[(long long)k * 1024 + n * 32 + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dw[i] = (float)red[0];
 }
 
 constexpr int STEM_WAVES = 4096;
@@ -661,10 +743,10 @@ constexpr int STEM_WAVES = 4096;
 // ======================================================================================== C ABI
 extern "C" {
 
-int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
-                      int B, int H, int W, int Cin, int Cout, int k, int stride,
-                      const float* scale, const float* shift, int act,
-                      const float* residual, int ldr, void* stream) {
+static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
+                         int B, int H, int W, int Cin, int Cout, int k, int stride,
+                         const float* scale, const float* shift, int act,
+                         const float* residual, int ldr, float* stats, int* bm_used, void* stream) {
     if (!x || !w || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -673,7 +755,7 @@ int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) return Y4_ERR_SHAPE;
     const int pad = (k - 1) / 2;
     ConvGeom g{};
-    g.src = x; g.wt = w; g.dst = y; g.scale = scale; g.shift = shift; g.res = residual;
+    g.src = x; g.wt = w; g.dst = y; g.scale = scale; g.shift = shift; g.res = residual; g.stats = stats;
     g.lds_ = ldx; g.ldd = ldy; g.ldr = ldr;
     g.B = B; g.Hs = H; g.Ws = W; g.Cs = Cin; g.Cs_valid = Cin;
     g.Hd = (H + 2 * pad - k) / stride + 1;
@@ -682,7 +764,38 @@ int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy
     const long long M = (long long)B * g.Hd * g.Wd;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cin; g.act = act;
-    return dispatch_gather<false>(g, y4_stream(stream));
+    return dispatch_gather<false>(g, y4_stream(stream), bm_used);
+}
+
+int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
+                      int B, int H, int W, int Cin, int Cout, int k, int stride,
+                      const float* scale, const float* shift, int act,
+                      const float* residual, int ldr, void* stream) {
+    return conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, scale, shift, act, residual, ldr, nullptr,
+                         nullptr, stream);
+}
+
+size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return 0;
+    const int pad = (k - 1) / 2;
+    const long long M = (long long)B * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
+    const long long rows = Cin == 3 ? (M + 255) / 256 : (M + 63) / 64;      // smallest M-tile of any variant
+    return (size_t)rows * 2 * Cout * sizeof(float);
+}
+
+int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y, int ldy,
+                              int B, int H, int W, int Cin, int Cout, int k, int stride,
+                              float* partials, size_t partial_bytes, long long* nparts_host, void* stream) {
+    if (!partials || !nparts_host) return Y4_ERR_NULL;
+    if (partial_bytes < y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;
+    int bm = 128;
+    const int rc = conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, nullptr, nullptr, Y4_ACT_LINEAR,
+                                 nullptr, 0, partials, &bm, stream);
+    if (rc != Y4_OK) return rc;
+    const int pad = (k - 1) / 2;
+    const long long M = (long long)B * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
+    *nparts_host = (M + bm - 1) / bm;
+    return Y4_OK;
 }
 
 size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
@@ -772,11 +885,12 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
 
 int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
                            const float* w, float* y, int ldy, int B, int H, int W, int Cout,
-                           const float* scale, const float* shift, int act, void* stream) {
+                           const float* scale, const float* shift, int act,
+                           float* bnstats_partials, void* stream) {
     if (!x || !w || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 32 || ldy < Cout) return Y4_ERR_SHAPE;
     StemGeom g{};
-    g.x = x; g.w = w; g.y = y; g.scale = scale; g.shift = shift;
+    g.x = x; g.w = w; g.y = y; g.scale = scale; g.shift = shift; g.stats = bnstats_partials;
     g.sxb = sxb; g.sxc = sxc; g.sxh = sxh; g.sxw = sxw; g.ldy = ldy;
     g.B = B; g.H = H; g.W = W; g.Cout = Cout; g.act = act;
     g.M = (long long)B * H * W;
@@ -793,7 +907,7 @@ int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long 
                              const float* dy, int lddy, float* dw, int B, int H, int W, int Cout,
                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dw || !workspace) return Y4_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 32 || lddy < Cout) return Y4_ERR_SHAPE;
+    if (B <= 0 || H <= 0 || W < 2 || Cout <= 0 || Cout > 32 || lddy < Cout) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_conv2d_stem_wgrad_workspace(B, H, W, Cout)) return Y4_ERR_WORKSPACE;
     StemWgradGeom g{};
     g.x = x; g.dy = dy; g.slabs = static_cast<float*>(workspace);
@@ -806,7 +920,7 @@ int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long 
     hipStream_t st = y4_stream(stream);
     hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(STEM_WAVES / 4), dim3(256), 0, st, g);
     Y4_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((Cout * 27 + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(Cout * 27), dim3(256), 0, st,
                        static_cast<const float*>(workspace), dw, STEM_WAVES, Cout);
     Y4_CHECK_LAUNCH();
     return Y4_OK;

@@ -32,21 +32,28 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // ---------------------------------------------------------------- BN statistics
 // Each thread sums <= ROWS_PER_THREAD rows in fp32, the block folds row groups through LDS and
 // issues one fp64 atomic per channel: var = E[y^2] - E[y]^2 is formed in fp64.
-constexpr int STAT_ROWS_PER_THREAD = 128;
+constexpr int STAT_ROWS_PER_THREAD = 128;     // upper bound; the launcher lowers it when M is small
+static inline int stat_rows(long long M, int rpb) {
+    // aim at >= ~2048 blocks (8 per CU) so the sweep runs at HBM rate also on the 19x19 / 38x38 maps
+    long long r = M / ((long long)rpb * 4096);
+    if (r < 4) r = 4;
+    if (r > STAT_ROWS_PER_THREAD) r = STAT_ROWS_PER_THREAD;
+    return (int)r;
+}
 
 __global__ __launch_bounds__(PW_THREADS) void bn_stats_kernel(const float* __restrict__ y, long long ldy,
-                                                              long long M, int C, int tpr, int rpb,
-                                                              double* __restrict__ acc /* [2][C] */) {
+                                                              long long M, int C, int tpr, int rpb, int nrows,
+                                                              float* __restrict__ part /* [blocks][2][C] */) {
     __shared__ float red[2][PW_THREADS][4];
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
-    const long long row0 = (long long)blockIdx.x * rpb * STAT_ROWS_PER_THREAD;
+    const long long row0 = (long long)blockIdx.x * rpb * nrows;
     for (int cb = 0; cb < C; cb += tpr * 4) {           // uniform trip count: barriers inside
         const int c0 = cb + cv * 4;
         const bool cok = c0 < C;
         f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int i = 0; i < STAT_ROWS_PER_THREAD; ++i) {
+#pragma unroll 8
+        for (int i = 0; i < nrows; ++i) {
             const long long m = row0 + (long long)i * rpb + rg;
             if (m < M && cok) {
                 const f32x4 v = ld4(y + m * ldy + c0);
@@ -58,20 +65,38 @@ __global__ __launch_bounds__(PW_THREADS) void bn_stats_kernel(const float* __res
         for (int e = 0; e < 4; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = ss[e]; }
         __syncthreads();
         if (rg == 0 && cok) {
-            double ds[4] = {0, 0, 0, 0}, dss[4] = {0, 0, 0, 0};
+            f32x4 ds = {0, 0, 0, 0}, dss = {0, 0, 0, 0};
             for (int g = 0; g < rpb; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    ds[e] += (double)red[0][g * tpr + cv][e];
-                    dss[e] += (double)red[1][g * tpr + cv][e];
+                    ds[e] += red[0][g * tpr + cv][e];
+                    dss[e] += red[1][g * tpr + cv][e];
                 }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(&acc[c0 + e], ds[e]);
-                atomicAdd(&acc[C + c0 + e], dss[e]);
-            }
+            float* pp = part + (long long)blockIdx.x * 2 * C;
+            st4(pp + c0, ds);
+            st4(pp + C + c0, dss);
         }
         __syncthreads();
+    }
+}
+
+// stage 2 of every per-channel reduction: partial rows [nparts][2][C] (fp32, each a sum over a few
+// thousand pixels at most) -> acc[2][C] in fp64.  <= 64 blocks, so the fp64 atomics do not contend.
+__global__ __launch_bounds__(PW_THREADS) void fold_partials_kernel(const float* __restrict__ part, long long nparts,
+                                                                   int C2, double* __restrict__ acc) {
+    const long long per = (nparts + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * per;
+    long long p1 = p0 + per;
+    if (p1 > nparts) p1 = nparts;
+    for (int c = threadIdx.x; c < C2; c += blockDim.x) {
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        long long p = p0;
+        for (; p + 3 < p1; p += 4) {
+            s0 += (double)part[p * C2 + c]; s1 += (double)part[(p + 1) * C2 + c];
+            s2 += (double)part[(p + 2) * C2 + c]; s3 += (double)part[(p + 3) * C2 + c];
+        }
+        for (; p < p1; ++p) s0 += (double)part[p * C2 + c];
+        if (p1 > p0) atomicAdd(&acc[c], (s0 + s1) + (s2 + s3));
     }
 }
 
@@ -124,11 +149,11 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dz, long long lddz, const float* __restrict__ y, long long ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-    long long M, int C, int tpr, int rpb, double* __restrict__ acc) {
+    long long M, int C, int tpr, int rpb, int nrows, float* __restrict__ part) {
     __shared__ float red[2][PW_THREADS][4];
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
-    const long long row0 = (long long)blockIdx.x * rpb * STAT_ROWS_PER_THREAD;
+    const long long row0 = (long long)blockIdx.x * rpb * nrows;
     for (int cb = 0; cb < C; cb += tpr * 4) {           // uniform trip count: barriers inside
         const int c0 = cb + cv * 4;
         const bool cok = c0 < C;
@@ -138,8 +163,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
             for (int e = 0; e < 4; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; }
         }
         f32x4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
-#pragma unroll 2
-        for (int i = 0; i < STAT_ROWS_PER_THREAD; ++i) {
+#pragma unroll 4
+        for (int i = 0; i < nrows; ++i) {
             const long long m = row0 + (long long)i * rpb + rg;
             if (m < M && cok) {
                 const f32x4 v = ld4(y + m * ldy + c0);
@@ -157,18 +182,16 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
         for (int e = 0; e < 4; ++e) { red[0][tid][e] = s[e]; red[1][tid][e] = sx[e]; }
         __syncthreads();
         if (rg == 0 && cok) {
-            double ds[4] = {0, 0, 0, 0}, dsx[4] = {0, 0, 0, 0};
+            f32x4 ds = {0, 0, 0, 0}, dsx = {0, 0, 0, 0};
             for (int g = 0; g < rpb; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    ds[e] += (double)red[0][g * tpr + cv][e];
-                    dsx[e] += (double)red[1][g * tpr + cv][e];
+                    ds[e] += red[0][g * tpr + cv][e];
+                    dsx[e] += red[1][g * tpr + cv][e];
                 }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(&acc[c0 + e], ds[e]);
-                atomicAdd(&acc[C + c0 + e], dsx[e]);
-            }
+            float* pp = part + (long long)blockIdx.x * 2 * C;
+            st4(pp + c0, ds);
+            st4(pp + C + c0, dsx);
         }
         __syncthreads();
     }
@@ -393,23 +416,57 @@ inline bool vec_ok(const void* p, long long ld, int C) {
 
 extern "C" {
 
-size_t y4_bn_workspace(int C) { return (size_t)2 * C * sizeof(double); }
+static long long bn_blocks(long long M, int C) {
+    const RowMap rm = row_map(C);
+    const long long rows_per_block = (long long)rm.rpb * stat_rows(M, rm.rpb);
+    return (M + rows_per_block - 1) / rows_per_block;
+}
+// [2C doubles][blocks * 2C floats]
+size_t y4_bn_workspace(long long M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)2 * C * sizeof(double) + (size_t)bn_blocks(M, C) * 2 * C * sizeof(float);
+}
+static int fold_partials(const float* part, long long nparts, int C, double* acc, hipStream_t st) {
+    if (hipMemsetAsync(acc, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return Y4_ERR_LAUNCH;
+    int blocks = (int)(nparts < 64 ? nparts : 64);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(blocks), dim3(PW_THREADS), 0, st, part, nparts, 2 * C, acc);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
 
 int y4_bn_stats_f32(const float* y, int ldy, long long M, int C, float* mean, float* invstd,
                     float* running_mean, float* running_var, long long* num_batches_tracked,
                     float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream) {
     if (!y || !mean || !invstd || !workspace) return Y4_ERR_NULL;
     if (!vec_ok(y, ldy, C) || M <= 0) return Y4_ERR_SHAPE;
-    if (workspace_bytes < y4_bn_workspace(C)) return Y4_ERR_WORKSPACE;
+    if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
     double* acc = static_cast<double*>(workspace);
-    if (hipMemsetAsync(acc, 0, y4_bn_workspace(C), st) != hipSuccess) return Y4_ERR_LAUNCH;
+    float* part = reinterpret_cast<float*>(acc + 2 * C);
     const RowMap rm = row_map(C);
-    const long long rows_per_block = (long long)rm.rpb * STAT_ROWS_PER_THREAD;
-    const long long blocks = (M + rows_per_block - 1) / rows_per_block;
+    const int nrows = stat_rows(M, rm.rpb);
+    const long long blocks = bn_blocks(M, C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, y, (long long)ldy, M, C,
-                       rm.tpr, rm.rpb, acc);
+                       rm.tpr, rm.rpb, nrows, part);
     Y4_CHECK_LAUNCH();
+    { const int rc = fold_partials(part, blocks, C, acc, st); if (rc != Y4_OK) return rc; }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, M, C, eps, momentum, mean,
+                       invstd, running_mean, running_var, num_batches_tracked);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long long M, int C,
+                                float* mean, float* invstd, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, float momentum, float eps,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    if (!partials || !mean || !invstd || !workspace) return Y4_ERR_NULL;
+    if (nparts <= 0 || M <= 0 || C <= 0) return Y4_ERR_SHAPE;
+    if (workspace_bytes < (size_t)2 * C * sizeof(double)) return Y4_ERR_WORKSPACE;
+    hipStream_t st = y4_stream(stream);
+    double* acc = static_cast<double*>(workspace);
+    { const int rc = fold_partials(partials, nparts, C, acc, st); if (rc != Y4_OK) return rc; }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, M, C, eps, momentum, mean,
                        invstd, running_mean, running_var, num_batches_tracked);
     Y4_CHECK_LAUNCH();
@@ -439,16 +496,17 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       long long M, int C, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
-    if (workspace_bytes < y4_bn_workspace(C)) return Y4_ERR_WORKSPACE;
+    if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
     double* acc = static_cast<double*>(workspace);
-    if (hipMemsetAsync(acc, 0, y4_bn_workspace(C), st) != hipSuccess) return Y4_ERR_LAUNCH;
+    float* part = reinterpret_cast<float*>(acc + 2 * C);
     const RowMap rm = row_map(C);
-    const long long rows_per_block = (long long)rm.rpb * STAT_ROWS_PER_THREAD;
-    const long long rblocks = (M + rows_per_block - 1) / rows_per_block;
+    const int nrows = stat_rows(M, rm.rpb);
+    const long long rblocks = bn_blocks(M, C);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((unsigned)rblocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz,
-                       y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, acc);
+                       y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, nrows, part);
     Y4_CHECK_LAUNCH();
+    { const int rc = fold_partials(part, rblocks, C, acc, st); if (rc != Y4_OK) return rc; }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, C, dgamma, dbeta);
     Y4_CHECK_LAUNCH();
     long long blocks = (M + rm.rpb - 1) / rm.rpb;

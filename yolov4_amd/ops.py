@@ -118,7 +118,7 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
             raise Y4Error('Cin=3 is supported for the 3x3/s1 stem only')
         sb, sc, sh, sw = x.stride()
         check(L.y4_conv2d_stem_fwd_f32(_ptr(x), sb, sc, sh, sw, _ptr(w), _ptr(out), ldy, B, H, W, Cout,
-                                       _ptr(scale), _ptr(shift), ACT_IDS[act], _stream()), 'conv2d_stem_fwd')
+                                       _ptr(scale), _ptr(shift), ACT_IDS[act], None, _stream()), 'conv2d_stem_fwd')
         return out
     x, ldx = as_nhwc(x)
     ldr = 0
@@ -127,6 +127,40 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
     check(L.y4_conv2d_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, B, H, W, Cin, Cout, k, s,
                               _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _stream()), 'conv2d_fwd')
     return out
+
+
+def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, eps):
+    """Training-mode conv: raw output y + BatchNorm batch statistics taken in the conv epilogue
+    (per-M-tile column sums, folded in fp64 by a second-stage kernel).  Returns (y, mean, invstd)."""
+    L = lib()
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    Ho, Wo = conv_out_hw(H, W, k, s)
+    y = empty_nhwc(B, Cout, Ho, Wo, x.device)
+    ldy = nhwc_pitch(y)
+    w = krsc(w)
+    pbytes = L.y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, s)
+    part = _ws(pbytes, x.device)
+    if Cin == 3:
+        if k != 3 or s != 1:
+            raise Y4Error('Cin=3 is supported for the 3x3/s1 stem only')
+        sb, sc, sh, sw = x.stride()
+        check(L.y4_conv2d_stem_fwd_f32(_ptr(x), sb, sc, sh, sw, _ptr(w), _ptr(y), ldy, B, H, W, Cout,
+                                       None, None, ACT_IDS['linear'], _ptr(part), _stream()), 'conv2d_stem_fwd')
+        nparts = (B * H * W + 255) // 256
+    else:
+        x, ldx = as_nhwc(x)
+        n = ctypes.c_longlong(0)
+        check(L.y4_conv2d_fwd_bnstats_f32(_ptr(x), ldx, _ptr(w), _ptr(y), ldy, B, H, W, Cin, Cout, k, s,
+                                          _ptr(part), pbytes, ctypes.byref(n), _stream()), 'conv2d_fwd_bnstats')
+        nparts = n.value
+    mean = torch.empty(Cout, device=x.device, dtype=torch.float32)
+    invstd = torch.empty(Cout, device=x.device, dtype=torch.float32)
+    ws = _ws(2 * Cout * 8, x.device)
+    check(L.y4_bn_finalize_partials_f32(_ptr(part), nparts, B * Ho * Wo, Cout, _ptr(mean), _ptr(invstd),
+                                        _ptr(running_mean), _ptr(running_var), _ptr(nbt), float(momentum), float(eps),
+                                        _ptr(ws), 2 * Cout * 8, _stream()), 'bn_finalize_partials')
+    return y, mean, invstd
 
 
 def conv_dgrad_raw(dy, w, x_shape, k, s):
@@ -172,7 +206,7 @@ def bn_stats_raw(y, running_mean, running_var, nbt, momentum, eps):
     y, ld = as_nhwc(y)
     mean = torch.empty(C, device=y.device, dtype=torch.float32)
     invstd = torch.empty(C, device=y.device, dtype=torch.float32)
-    nbytes = L.y4_bn_workspace(C)
+    nbytes = L.y4_bn_workspace(B * H * W, C)
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_stats_f32(_ptr(y), ld, B * H * W, C, _ptr(mean), _ptr(invstd), _ptr(running_mean),
                             _ptr(running_var), _ptr(nbt), float(momentum), float(eps), _ptr(ws), nbytes, _stream()),
@@ -201,7 +235,7 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act):
     dy = empty_nhwc(B, C, H, W, y.device)
     dgamma = torch.empty(C, device=y.device, dtype=torch.float32)
     dbeta = torch.empty(C, device=y.device, dtype=torch.float32)
-    nbytes = L.y4_bn_workspace(C)
+    nbytes = L.y4_bn_workspace(B * H * W, C)
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
@@ -266,9 +300,8 @@ class ConvBNActFn(torch.autograd.Function):
         if bn and training:
             if x.shape[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[1] <= 1:
                 raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
-            y = conv_fwd_raw(x, weight, k, s)
-            mean, invstd = bn_stats_raw(y, cfg['running_mean'], cfg['running_var'], cfg['nbt'],
-                                        cfg['momentum'], cfg['eps'])
+            y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
+                                                   cfg['nbt'], cfg['momentum'], cfg['eps'])
             z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual)
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
