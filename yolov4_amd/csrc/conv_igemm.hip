@@ -199,13 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     const int a_frag = (wm * WTM + fr) * LDS_PITCH + fh * 4;
     const int b_frag = (wn * WTN + fr) * LDS_PITCH + fh * 4;
 
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_tile();                  // global loads in flight under the MFMAs
-        const float* as = As + cur * BM * LDS_PITCH + a_frag;
-        const float* bs = Bs + cur * BN * LDS_PITCH + b_frag;
+    auto mfma_steps = [&](const float* as, const float* bs, int u0, int u1) {
 #pragma unroll
-        for (int u = 0; u < BK / 8; ++u) {
+        for (int u = u0; u < u1; ++u) {
             f32x4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDS_PITCH + u * 8);
@@ -219,6 +215,18 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
         }
+    };
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        const float* as = As + cur * BM * LDS_PITCH + a_frag;
+        const float* bs = Bs + cur * BN * LDS_PITCH + b_frag;
+        // first quarter of the MFMAs is issued before the next tile's address arithmetic + buffer loads,
+        // so that block runs in the shadow of MFMAs already queued on the matrix pipe
+        mfma_steps(as, bs, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) load_tile();                  // global loads in flight under the remaining MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_steps(as, bs, 1, BK / 8);
         if (kt + 1 < KT) store_tile(cur ^ 1);
         __syncthreads();
     }
