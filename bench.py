@@ -86,6 +86,7 @@ class ConvTimer:
             return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k, (x.shape[1], Cout, k, s, x.shape[2])
 
         ops.conv_fwd_raw = bracket(ops.conv_fwd_raw, 'conv_fwd', f_fwd)
+        ops.conv_fwd_bnstats_raw = bracket(ops.conv_fwd_bnstats_raw, 'conv_fwd', f_fwd)   # conv + BN-stat epilogue + fold
         ops.conv_dgrad_raw = bracket(ops.conv_dgrad_raw, 'conv_dgrad', f_dgrad)
         ops.conv_wgrad_raw = bracket(ops.conv_wgrad_raw, 'conv_wgrad', f_wgrad)
 
@@ -110,6 +111,23 @@ class ConvTimer:
         for (kind, cin, cout, k, s, h), v in rows:
             lines.append(f'{kind:10s} {cin:5d} {cout:5d} {k} {s} {h:4d} {v[2] / steps:7.1f} {v[1] / steps * 1e3:8.2f} {v[0] / v[1] / 1e12:8.1f}')
         return '\n'.join(lines)
+
+
+def pmc_traffic(kind):
+    """HBM-side bytes per launch of the kernel family (largest tile variant), from the separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/, corrected as
+    MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes).  PMC counters cannot
+    be read from inside the process, so this is the recorded measurement or None."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic_per_kernel.json')
+    if not os.path.isfile(path):
+        return None
+    tab = json.load(open(path))
+    want = {'conv_fwd': 'conv_gather_mfma_f32<128, 128, 2, 2, false', 'conv_dgrad': 'conv_gather_mfma_f32<128, 128, 2, 2, true',
+            'conv_wgrad': 'conv_wgrad_mfma_f32<128, 128>'}[kind]
+    for k, v in tab.items():
+        if want in k:
+            return v['hbm_bytes_per_launch_corrected']
+    return None
 
 
 def cpu_baseline(size, batch):
@@ -214,11 +232,12 @@ def main():
         if timer.rec:
             summ = timer.summary()
             dom = max(summ, key=lambda k: summ[k]['seconds'])
-            kname = {'conv_fwd': 'conv_gather_mfma_f32<..,false> (forward implicit GEMM)',
+            kname = {'conv_fwd': 'conv_gather_mfma_f32<..,false> (forward implicit GEMM, BN-stat epilogue + fold kernels included)',
                      'conv_dgrad': 'conv_gather_mfma_f32<..,true> (dgrad implicit GEMM, incl. filter transpose)',
                      'conv_wgrad': 'conv_wgrad_mfma_f32 (+ slab reduce)'}[dom]
             out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                               'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS,
+                               'traffic': pmc_traffic(dom),
                                'kernel': kname,
                                'avg_launch_ms': summ[dom]['seconds'] / summ[dom]['launches'] * 1e3,
                                'launches': summ[dom]['launches'],

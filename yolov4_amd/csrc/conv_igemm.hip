@@ -10,12 +10,13 @@
 // Tile: 256 threads = 4 waves; each wave owns TM x TN tiles of 32x32 (16 accumulator VGPRs each).
 // LDS: [rows][BK + 4] floats (row pitch 144 B -> ds_read_b128 conflict-free across the 16-lane
 // groups), double buffered, register-staged global loads issued one K-tile ahead.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
 constexpr int BK = 32;            // K-tile depth (floats)
-constexpr int LDS_PITCH = BK + 4; // padded row pitch (floats): 36*4 = 144 B
+
 
 struct ConvGeom {
     // gathered ("source") tensor and produced ("dest") tensor, both NHWC with pitch
@@ -43,9 +44,13 @@ struct ConvGeom {
 // TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
 // TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
 //                     (stride 2: exact division is guaranteed by the parity-class tiling)
-template <int BM, int BN, int WM, int WN, bool TRANSPOSED>
-__global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g) {
-    constexpr int PA = BM / 32, PB = BN / 32;         // load passes (32 rows x 8 lanes x 16 B per pass)
+template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int BKT = 32>
+__global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void conv_gather_mfma_f32(const ConvGeom g) {
+    constexpr int LPR = BKT / 4;                      // lanes per tile row (16 B each)
+    constexpr int RPP = 256 / LPR;                    // rows per load pass
+    constexpr int PA = BM / RPP, PB = BN / RPP;       // load passes
+    constexpr int LDS_PITCH = BKT + 4;                // 144-B / 80-B row pitch: conflict-free ds_read_b128
+    constexpr int BK = BKT;
     constexpr int WTM = BM / WM, WTN = BN / WN;       // wave tile
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4, "4 waves");
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     const int n0 = nt * BN;
     const int nr = (g.k - r0 + tstep - 1) / tstep, nq = (g.k - q0 + tstep - 1) / tstep;
 
-    const int lrow = tid >> 3, kc = tid & 7;
+    const int lrow = tid / LPR, kc = tid % LPR;
 
     // ---- per-thread A-row bookkeeping (rows are fixed for the whole K loop); byte offsets, 32 bit
     const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, g.src_bytes);
@@ -97,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int row = p * 32 + lrow;
+        const int row = p * RPP + lrow;
         const int i = mt_local * BM + row;
         int b, hd, wd;
         if (!classed) {
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
     unsigned b_off[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-        const int n = n0 + p * 32 + lrow;
+        const int n = n0 + p * RPP + lrow;
         b_off[p] = n < g.N ? (unsigned)n * (unsigned)g.K * 4u + kc * 16u : OOB;
     }
 
@@ -174,11 +179,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_mfma_f32(const ConvGeom g)
                 for (int e = 0; e < 4; ++e)
                     if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
             }
-            *reinterpret_cast<f32x4*>(as + (p * 32 + lrow) * LDS_PITCH + kc * 4) = v;
+            *reinterpret_cast<f32x4*>(as + (p * RPP + lrow) * LDS_PITCH + kc * 4) = v;
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<f32x4*>(bs + (p * 32 + lrow) * LDS_PITCH + kc * 4) = rb[p];
+            *reinterpret_cast<f32x4*>(bs + (p * RPP + lrow) * LDS_PITCH + kc * 4) = rb[p];
         if (++st_cc == CC) st_cc = 0;
     };
 
@@ -302,7 +307,7 @@ __global__ void transpose_filter_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool TR>
+template <int BM, int BN, int WM, int WN, bool TR, int BKT = 32>
 int launch_gather(const ConvGeom& g0, hipStream_t st) {
     ConvGeom g = g0;
     if (TR && g.stride == 2) {
@@ -328,8 +333,8 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
         if (sb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;   // 32-bit buffer offsets
         g.src_bytes = (unsigned)sb; g.wt_bytes = (unsigned)wb;
     }
-    const size_t smem = 2ull * (BM + BN) * LDS_PITCH * sizeof(float) + BM * sizeof(int);
-    auto kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR>;
+    const size_t smem = 2ull * (BM + BN) * (BKT + 4) * sizeof(float) + BM * sizeof(int);
+    auto kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR, BKT>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -355,6 +360,8 @@ template <bool TR>
 int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
     if (bm_used) *bm_used = 128;
     if (g.N > 64) {
+        static const char* var = getenv("Y4_CONV_VARIANT");
+        if (var && var[0] == 'k') return launch_gather<128, 128, 2, 2, TR, 16>(g, st);   // experiment: BK=16, 3 blocks/CU
         // 2 resident blocks per CU (LDS) -> 512 slots.  When 128-row tiles fill the last round badly
         // (e.g. 724 blocks = 1.41 rounds at 19x19 maps), 64-row tiles (+8 % per-flop cost) win.
         const long long nt = (g.N + 127) / 128;
