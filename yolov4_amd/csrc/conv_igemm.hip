@@ -360,19 +360,25 @@ template <bool TR>
 int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
     if (bm_used) *bm_used = 128;
     if (g.N > 64) {
-        static const char* var = getenv("Y4_CONV_VARIANT");
-        if (var && var[0] == 'k') return launch_gather<128, 128, 2, 2, TR, 16>(g, st);   // experiment: BK=16, 3 blocks/CU
-        // 2 resident blocks per CU (LDS) -> 512 slots.  When 128-row tiles fill the last round badly
-        // (e.g. 724 blocks = 1.41 rounds at 19x19 maps), 64-row tiles (+8 % per-flop cost) win.
+        // LDS allows 2 resident blocks per CU at BK = 32 (74 KB) and 3 at BK = 16 (41 KB).  1x1 convs have
+        // short K loops (4..32 tiles), so prologue/epilogue time matters: the third block covers it
+        // (+5..10 % measured); on the long 3x3 loops the two depths tie and BK = 32 halves the barriers.
+        const bool short_k = g.k == 1;
+        const long long slots = short_k ? 768 : 512;
+        // When 128-row tiles fill the last round of resident blocks badly (e.g. 724 blocks = 1.41 rounds
+        // at 19x19 maps), 64-row tiles (+8 % per-flop cost) win.
         const long long nt = (g.N + 127) / 128;
         const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
-        const double c128 = (double)((b128 + 511) / 512) * 128.0;
-        const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.08;
+        const double c128 = (double)((b128 + slots - 1) / slots) * 128.0;
+        const double c64 = (double)((b64 + slots - 1) / slots) * 64.0 * 1.08;
         if (c64 < c128 && !(TR && g.stride == 2)) {
             if (bm_used) *bm_used = 64;
-            return launch_gather<64, 128, 2, 2, TR>(g, st);
+            return short_k ? launch_gather<64, 128, 2, 2, TR, 16>(g, st) : launch_gather<64, 128, 2, 2, TR>(g, st);
         }
-        return launch_gather<128, 128, 2, 2, TR>(g, st);
+        return short_k ? launch_gather<128, 128, 2, 2, TR, 16>(g, st) : launch_gather<128, 128, 2, 2, TR>(g, st);
+    }
+    if (g.k == 1) {      // HBM-bound 1x1 layers at 304^2 / 152^2: more resident blocks = more loads in flight
+        if (g.N > 32) return launch_gather<128, 64, 2, 2, TR, 16>(g, st);
     }
     if (g.N > 32) return launch_gather<128, 64, 2, 2, TR>(g, st);
     return launch_gather<128, 32, 4, 1, TR>(g, st);
@@ -568,6 +574,7 @@ void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int stride, Wgrad
         double eff = (double)blocks / (double)(rounds * slots);
         if (rounds > 6) eff = 1.0;                           // enough rounds: tail is amortised
         if (eff > best_eff + 0.02) { best_eff = eff; best_s = sp; }
+        if (blocks >= 2ll * slots && eff >= 0.93) break;     // good enough: fewer slabs to write and fold
         if (blocks >= 6ll * slots) break;
     }
     g.chunks_per_split = (chunks + best_s - 1) / best_s;
