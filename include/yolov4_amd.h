@@ -47,6 +47,13 @@ int y4_version(void);
 /* number of visible HIP devices whose arch is gfx950 (0 if none) */
 int y4_device_count(void);
 
+/* Arithmetic of the conv implicit GEMMs (process-wide):
+ *   0  v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain (default);
+ *   1  "bf16x3": operands split exactly into 3 bf16 pieces, six bf16 MFMAs per product, fp32
+ *      accumulate; dropped terms <= 2^-23 |a*b| -> fp32-grade results at 6/16 of the MFMA cost. */
+int y4_set_conv_mode(int mode);
+int y4_get_conv_mode(void);
+
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d inside ConvBNAct.forward, darknet/darknet.py:31-36,53-54
  * (k in {1,3}, stride in {1,2}, pad=(k-1)//2, dilation 1, groups 1).

@@ -27,6 +27,8 @@ PROTOTYPES = {
     'y4_strerror': (c_char_p, [I]),
     'y4_version': (I, []),
     'y4_device_count': (I, []),
+    'y4_set_conv_mode': (I, [I]),
+    'y4_get_conv_mode': (I, []),
     'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
     'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P]),
@@ -82,6 +84,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = handle
+        if os.environ.get('Y4_CONV_MODE'):
+            handle.y4_set_conv_mode(int(os.environ['Y4_CONV_MODE']))
     return _lib
 
 

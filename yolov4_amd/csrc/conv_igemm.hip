@@ -293,6 +293,273 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void conv_gather_mfma_f32
     }
 }
 
+// =====================================================================================================
+// Split-bf16 variant of the gather kernel ("bf16x3"): every fp32 operand is split EXACTLY into three bf16
+// pieces (8+8+8 mantissa bits, truncation split: x = x1 + x2 + x3) when its tile is staged into LDS, and
+// the product is formed on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, products exact, fp32
+// accumulate) as the six leading terms  a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1.  The dropped terms are
+// <= 2^-23 |a b|, i.e. the result carries fp32-grade error (comparable to an fp32 FMA chain's rounding)
+// at 6/16 of the fp32-MFMA cost.  Same tiling / gather / epilogues as conv_gather_mfma_f32.
+// LDS: 3 planes x [rows][32 + 8] bf16 per operand (80-B pitch: conflict-free ds_read_b128), single stage,
+// register prefetch of the next K-tile under the MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// pack the upper halves (= truncated bf16) of two fp32 words: result = {hi16(x1), hi16(x0)}
+__device__ __forceinline__ unsigned pack_hi16(unsigned x1, unsigned x0) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
+
+__device__ __forceinline__ void split3x4(const f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+    unsigned h1[4], h2[4], h3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h1[e] = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(h1[e] & 0xffff0000u);     // exact
+        h2[e] = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(h2[e] & 0xffff0000u);       // exact, <= 8 significant bits left
+        h3[e] = __float_as_uint(r2);
+    }
+    p1[0] = pack_hi16(h1[1], h1[0]); p1[1] = pack_hi16(h1[3], h1[2]);
+    p2[0] = pack_hi16(h2[1], h2[0]); p2[1] = pack_hi16(h2[3], h2[2]);
+    p3[0] = pack_hi16(h3[1], h3[0]); p3[1] = pack_hi16(h3[3], h3[2]);
+}
+
+template <int BM, int BN, int WM, int WN, bool TRANSPOSED>
+__global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
+    constexpr int BK = 32;
+    constexpr int PITCH_B = 80;                        // bytes per LDS row (32 bf16 + 16 B pad)
+    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;                        // [3][BM][80 B]
+    unsigned char* Bs = smem_b + 3 * BM * PITCH_B;     // [3][BN][80 B]
+    int* row_m = reinterpret_cast<int*>(smem_b + 3 * (BM + BN) * PITCH_B);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int r0 = 0, q0 = 0, tstep = 1;
+    int ph = 0, pw = 0, mt_local, nt;
+    const bool classed = TRANSPOSED && g.stride == 2;
+    if (!classed) {
+        const int lt = y4_xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+        mt_local = lt / g.ntiles;
+        nt = lt - mt_local * g.ntiles;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        int c = 0;
+        while (c < 3 && slot >= g.cls_slot0[c + 1]) ++c;
+        const int per = g.cls_slot0[c + 1] - g.cls_slot0[c];
+        const int t = xcd * per + (slot - g.cls_slot0[c]);
+        const int tiles_c = (g.cls_tile0[c + 1] - g.cls_tile0[c]) * g.ntiles;
+        if (t >= tiles_c) return;
+        mt_local = t / g.ntiles;
+        nt = t - mt_local * g.ntiles;
+        ph = (3 - c) >> 1; pw = (3 - c) & 1;
+        r0 = (ph + g.pad) & 1; q0 = (pw + g.pad) & 1; tstep = 2;
+    }
+    const int n0 = nt * BN;
+    const int nr = (g.k - r0 + tstep - 1) / tstep, nq = (g.k - q0 + tstep - 1) / tstep;
+    const int lrow = tid >> 3, kc = tid & 7;
+
+    const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, g.src_bytes);
+    const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt, g.wt_bytes);
+    const unsigned OOB = 0xffffffffu;
+    unsigned a_base[PA];
+    int a_h[PA], a_w[PA];
+    bool a_ok[PA];
+    const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int row = p * 32 + lrow;
+        const int i = mt_local * BM + row;
+        int b, hd, wd;
+        if (!classed) {
+            a_ok[p] = i < g.M;
+            const int ii = a_ok[p] ? i : 0;
+            b = ii / (g.Hd * g.Wd);
+            const int rem = ii - b * (g.Hd * g.Wd);
+            hd = rem / g.Wd; wd = rem - hd * g.Wd;
+        } else {
+            const int hc = g.cls_h[ph], wc = g.cls_w[pw];
+            a_ok[p] = i < g.B * hc * wc;
+            const int ii = a_ok[p] ? i : 0;
+            b = ii / (hc * wc);
+            const int rem = ii - b * (hc * wc);
+            const int hh = rem / wc;
+            hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
+        }
+        if (kc == 0) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
+        a_base[p] = (unsigned)b * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
+        if (!TRANSPOSED) { a_h[p] = hd * g.stride - g.pad; a_w[p] = wd * g.stride - g.pad; }
+        else { a_h[p] = hd + g.pad; a_w[p] = wd + g.pad; }
+    }
+    unsigned b_off[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int n = n0 + p * 32 + lrow;
+        b_off[p] = n < g.N ? (unsigned)n * (unsigned)g.K * 4u + kc * 16u : OOB;
+    }
+
+    f32x4 ra[PA], rb[PB];
+    const int CC = g.Cs / BK;
+    int r = r0, q = q0, cc = 0;
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int hi, wi;
+            bool ok = a_ok[p];
+            if (!TRANSPOSED) {
+                hi = a_h[p] + r; wi = a_w[p] + q;
+                ok = ok && (unsigned)hi < (unsigned)g.Hs && (unsigned)wi < (unsigned)g.Ws;
+            } else {
+                const int th = a_h[p] - r, tw = a_w[p] - q;
+                hi = th; wi = tw;
+                if (g.stride == 2) { hi = th >> 1; wi = tw >> 1; }
+                ok = ok && th >= 0 && tw >= 0 && hi < g.Hs && wi < g.Ws;
+            }
+            const unsigned off = a_base[p] + (unsigned)(hi * g.Ws + wi) * pix_bytes;
+            ra[p] = y4_buf_load4(src_rsrc, ok ? off : OOB, (unsigned)(cc * BK) * 4u);
+        }
+        const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 4u);
+#pragma unroll
+        for (int p = 0; p < PB; ++p) rb[p] = y4_buf_load4(wt_rsrc, b_off[p], koff);
+        if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } }
+    };
+    int st_cc = 0;
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            f32x4 v = ra[p];
+            if (TRANSPOSED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
+            }
+            u32x2 p1, p2, p3;
+            split3x4(v, p1, p2, p3);
+            unsigned char* d = As + (p * 32 + lrow) * PITCH_B + kc * 8;
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + BM * PITCH_B) = p2;
+            *reinterpret_cast<u32x2*>(d + 2 * BM * PITCH_B) = p3;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            u32x2 p1, p2, p3;
+            split3x4(rb[p], p1, p2, p3);
+            unsigned char* d = Bs + (p * 32 + lrow) * PITCH_B + kc * 8;
+            *reinterpret_cast<u32x2*>(d) = p1;
+            *reinterpret_cast<u32x2*>(d + BN * PITCH_B) = p2;
+            *reinterpret_cast<u32x2*>(d + 2 * BN * PITCH_B) = p3;
+        }
+        if (++st_cc == CC) st_cc = 0;
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int KT = nr * nq * CC;
+    load_tile();
+    store_tile();
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned char* a_frag = As + (wm * WTM + fr) * PITCH_B + fh * 16;
+    const unsigned char* b_frag = Bs + (wn * WTN + fr) * PITCH_B + fh * 16;
+
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) load_tile();                  // next tile's loads fly under this tile's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 fa[TM][3], fb[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * PITCH_B + i * 32 * PITCH_B + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fb[j][pl] = *reinterpret_cast<const bf16x8*>(b_frag + pl * BN * PITCH_B + j * 32 * PITCH_B + ks * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    f32x16 c = acc[i][j];                 // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        __syncthreads();                               // every wave is done reading this stage
+        if (kt + 1 < KT) store_tile();                 // split + write the prefetched tile
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + fr;
+        const bool nok = n < g.N;
+        const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
+        const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int rbase = wm * WTM + i * 32 + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = row_m[rbase + (e & 3) + 8 * (e >> 2)];
+                if (nok && m >= 0) {
+                    float v = acc[i][j][e] * sc + sh;
+                    v = y4_act(v, g.act);
+                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    g.dst[(long long)m * g.ldd + n] = v;
+                }
+            }
+        }
+    }
+    if (!TRANSPOSED && g.stats) {
+        float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the K loop ended with a barrier
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float v = acc[i][j][e]; cs += v; css += v * v; }
+            cs += __shfl_xor(cs, 32, 64);
+            css += __shfl_xor(css, 32, 64);
+            if (fh == 0) {
+                const int c = wn * WTN + j * 32 + fr;
+                red[(wm * BN + c) * 2 + 0] = cs;
+                red[(wm * BN + c) * 2 + 1] = css;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
+            const int n = n0 + c;
+            if (n < g.N) {
+                g.stats[((long long)mt_local * 2 + 0) * g.N + n] = cs;
+                g.stats[((long long)mt_local * 2 + 1) * g.N + n] = css;
+            }
+        }
+    }
+}
+
 // [Cout][k][k][Cin] -> [Cin][k][k][Cout4] (zero padded to a multiple of 32 output channels)
 __global__ void transpose_filter_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                         int Cout, int Cin, int kk, int Cout_pad) {
@@ -307,7 +574,7 @@ __global__ void transpose_filter_kernel(const float* __restrict__ w, float* __re
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool TR, int BKT = 32>
+template <int BM, int BN, int WM, int WN, bool TR, int BKT = 32, bool SPLIT = false>
 int launch_gather(const ConvGeom& g0, hipStream_t st) {
     ConvGeom g = g0;
     if (TR && g.stride == 2) {
@@ -333,8 +600,11 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
         if (sb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;   // 32-bit buffer offsets
         g.src_bytes = (unsigned)sb; g.wt_bytes = (unsigned)wb;
     }
-    const size_t smem = 2ull * (BM + BN) * (BKT + 4) * sizeof(float) + BM * sizeof(int);
-    auto kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR, BKT>;
+    const size_t smem = SPLIT ? 3ull * (BM + BN) * 80 + BM * sizeof(int)
+                              : 2ull * (BM + BN) * (BKT + 4) * sizeof(float) + BM * sizeof(int);
+    void (*kern)(const ConvGeom);
+    if constexpr (SPLIT) kern = conv_gather_bf16x3<BM, BN, WM, WN, TR>;
+    else kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR, BKT>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -356,9 +626,26 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
     return Y4_OK;
 }
 
+int g_conv_mode = 0;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs)
+
 template <bool TR>
 int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
     if (bm_used) *bm_used = 128;
+    if (g_conv_mode == 1) {
+        if (g.N > 64) {
+            const long long nt = (g.N + 127) / 128;
+            const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
+            const double c128 = (double)((b128 + 511) / 512) * 128.0;
+            const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.10;
+            if (c64 < c128 && !(TR && g.stride == 2)) {
+                if (bm_used) *bm_used = 64;
+                return launch_gather<64, 128, 2, 2, TR, 32, true>(g, st);
+            }
+            return launch_gather<128, 128, 2, 2, TR, 32, true>(g, st);
+        }
+        if (g.N > 32) return launch_gather<128, 64, 2, 2, TR, 32, true>(g, st);
+        return launch_gather<128, 32, 4, 1, TR, 32, true>(g, st);
+    }
     if (g.N > 64) {
         // LDS allows 2 resident blocks per CU at BK = 32 (74 KB) and 3 at BK = 16 (41 KB).  1x1 convs have
         // short K loops (4..32 tiles), so prologue/epilogue time matters: the third block covers it
@@ -534,6 +821,175 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
     }
 }
 
+// Split-bf16 ("bf16x3") wgrad: same math as conv_wgrad_mfma_f32, operands split exactly into three bf16
+// planes while being transposed into LDS as [n or j][32 pixels] rows (80-B pitch), so the fragment reads
+// are the plain ds_read_b128 of the gather kernel.  Each thread owns one 4-pixel x 4-channel block of
+// each operand per 32-pixel chunk (4 coalesced 16-B loads, a 4x4 register transpose folded into the
+// bf16 packing, 12 ds_write_b64).
+template <int TN_, int TJ_>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3(const WgradGeom g) {
+    constexpr int MI = TN_ / 64, MJ = TJ_ / 64;
+    constexpr int PITCH_B = 80;
+    constexpr int NBLK_A = 8 * (TN_ / 4), NBLK_B = 8 * (TJ_ / 4);     // 4x4 blocks per chunk (<= 256)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* As = smem_b;                          // [3][TN_][80 B]
+    unsigned char* Bs = smem_b + 3 * TN_ * PITCH_B;      // [3][TJ_][80 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles = g.ntn * g.ntj;
+    int bid = y4_xcd_remap(blockIdx.x, tiles * g.splits);
+    const int split = bid / tiles;
+    bid -= split * tiles;
+    const int tn = bid / g.ntj, tj = bid - tn * g.ntj;
+    const int n0 = tn * TN_, j0 = tj * TJ_;
+
+    const int pg = tid & 7, cg = tid >> 3;               // pixel group (4 px), channel group (4 ch)
+    const bool a_act = tid < NBLK_A, b_act = tid < NBLK_B;
+    const int Cout4 = (g.Cout + 3) & ~3;
+    const bool an_ok = a_act && (n0 + cg * 4) < Cout4;
+    const int j = j0 + cg * 4;
+    const bool bj_ok = b_act && j < g.J;
+    int jr = 0, jq = 0, jc = 0;
+    if (bj_ok) { const int tap = j / g.Cin; jc = j - tap * g.Cin; jr = tap / g.k; jq = tap - jr * g.k; }
+
+    const int chunk0 = split * g.chunks_per_split;
+    int nchunks = (g.M + 31) / 32 - chunk0;
+    if (nchunks > g.chunks_per_split) nchunks = g.chunks_per_split;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc = y4_make_rsrc(g.x, g.x_bytes);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = y4_make_rsrc(g.dy, g.dy_bytes);
+    const unsigned OOB = 0xffffffffu;
+    int pb_b[4], pb_h[4], pb_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = chunk0 * 32 + pg * 4 + i;
+        const int pp = pix < g.M ? pix : 0;
+        pb_b[i] = pp / (g.Ho * g.Wo);
+        const int rem = pp - pb_b[i] * (g.Ho * g.Wo);
+        pb_h[i] = rem / g.Wo;
+        pb_w[i] = rem - pb_h[i] * g.Wo;
+    }
+    const unsigned a_off0 = an_ok ? (unsigned)(chunk0 * 32 + pg * 4) * (unsigned)g.lddy * 4u + (unsigned)(n0 + cg * 4) * 4u : OOB;
+    const unsigned dy_pix_bytes = (unsigned)g.lddy * 4u;
+    const unsigned chunk_bytes = 32u * dy_pix_bytes;
+    const unsigned x_pix_bytes = (unsigned)g.ldx * 4u;
+
+    f32x4 ra[4], rb[4];
+    int ld_chunk = 0;
+    auto load_chunk = [&]() {
+        const int pbase = (chunk0 + ld_chunk) * 32 + pg * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = an_ok && pbase + i < g.M;
+            ra[i] = y4_buf_load4(dy_rsrc, ok ? a_off0 + (unsigned)i * dy_pix_bytes : OOB, (unsigned)ld_chunk * chunk_bytes);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hi = pb_h[i] * g.stride - g.pad + jr, wi = pb_w[i] * g.stride - g.pad + jq;
+            const bool ok = bj_ok && pbase + i < g.M && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            const unsigned off = (unsigned)((pb_b[i] * g.H + hi) * g.W + wi) * x_pix_bytes + (unsigned)jc * 4u;
+            rb[i] = y4_buf_load4(x_rsrc, ok ? off : OOB, 0u);
+            pb_w[i] += 32;
+            while (pb_w[i] >= g.Wo) { pb_w[i] -= g.Wo; if (++pb_h[i] == g.Ho) { pb_h[i] = 0; ++pb_b[i]; } }
+        }
+        ++ld_chunk;
+    };
+    // split 4 pixels x 4 channels and write the 4 channel rows (3 planes each) transposed
+    auto split_store = [&](const f32x4 (&v)[4], unsigned char* base, int rows) {
+        unsigned h1[4][4], h2[4][4], h3[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h1[i][e] = __float_as_uint(v[i][e]);
+                const float r1 = v[i][e] - __uint_as_float(h1[i][e] & 0xffff0000u);
+                h2[i][e] = __float_as_uint(r1);
+                const float r2 = r1 - __uint_as_float(h2[i][e] & 0xffff0000u);
+                h3[i][e] = __float_as_uint(r2);
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            unsigned char* d = base + (cg * 4 + e) * PITCH_B + pg * 8;
+            u32x2 p;
+            p[0] = pack_hi16(h1[1][e], h1[0][e]); p[1] = pack_hi16(h1[3][e], h1[2][e]);
+            *reinterpret_cast<u32x2*>(d) = p;
+            p[0] = pack_hi16(h2[1][e], h2[0][e]); p[1] = pack_hi16(h2[3][e], h2[2][e]);
+            *reinterpret_cast<u32x2*>(d + rows * PITCH_B) = p;
+            p[0] = pack_hi16(h3[1][e], h3[0][e]); p[1] = pack_hi16(h3[3][e], h3[2][e]);
+            *reinterpret_cast<u32x2*>(d + 2 * rows * PITCH_B) = p;
+        }
+    };
+    auto store_chunk = [&]() {
+        if (a_act) split_store(ra, As, TN_);
+        if (b_act) split_store(rb, Bs, TJ_);
+    };
+
+    f32x16 acc[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < MJ; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const unsigned char* a_frag = As + (wm * (TN_ / 2) + fr) * PITCH_B + fh * 16;
+    const unsigned char* b_frag = Bs + (wn * (TJ_ / 2) + fr) * PITCH_B + fh * 16;
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk();
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (ch + 1 < nchunks) load_chunk();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[MI][3], fb[MJ][3];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * TN_ * PITCH_B + i * 32 * PITCH_B + ks * 32);
+#pragma unroll
+                for (int jj = 0; jj < MJ; ++jj)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        fb[jj][pl] = *reinterpret_cast<const bf16x8*>(b_frag + pl * TJ_ * PITCH_B + jj * 32 * PITCH_B + ks * 32);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < MJ; ++jj) {
+                        f32x16 c = acc[i][jj];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[jj][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[jj][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[jj][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][0], c, 0, 0, 0);
+                        acc[i][jj] = c;
+                    }
+            }
+            __syncthreads();
+            if (ch + 1 < nchunks) store_chunk();
+            __syncthreads();
+        }
+    }
+    float* out = g.out + (long long)split * g.Cout * g.J;
+#pragma unroll
+    for (int jj = 0; jj < MJ; ++jj) {
+        const int jcol = j0 + wn * (TJ_ / 2) + jj * 32 + fr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int nb = n0 + wm * (TN_ / 2) + i * 32 + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int n = nb + (e & 3) + 8 * (e >> 2);
+                if (n < g.Cout && jcol < g.J) out[(long long)n * g.J + jcol] = acc[i][jj][e];
+            }
+        }
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                    long long n, int splits) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
@@ -577,14 +1033,17 @@ void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int stride, Wgrad
         if (blocks >= 2ll * slots && eff >= 0.93) break;     // good enough: fewer slabs to write and fold
         if (blocks >= 6ll * slots) break;
     }
+    { static const char* fs = getenv("Y4_WGRAD_SPLITS"); if (fs) { best_s = atoi(fs); if (best_s > max_s) best_s = max_s; if (best_s < 1) best_s = 1; } }
     g.chunks_per_split = (chunks + best_s - 1) / best_s;
     g.splits = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
 }
 
-template <int TN_, int TJ_>
+template <int TN_, int TJ_, bool SPLIT = false>
 int launch_wgrad(const WgradGeom& g, hipStream_t st) {
-    const size_t smem = 2ull * 32 * (TN_ + TJ_) * sizeof(float);
-    auto kern = conv_wgrad_mfma_f32<TN_, TJ_>;
+    const size_t smem = SPLIT ? 3ull * (TN_ + TJ_) * 80 : 2ull * 32 * (TN_ + TJ_) * sizeof(float);
+    void (*kern)(const WgradGeom);
+    if constexpr (SPLIT) kern = conv_wgrad_bf16x3<TN_, TJ_>;
+    else kern = conv_wgrad_mfma_f32<TN_, TJ_>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -765,6 +1224,13 @@ constexpr int STEM_WAVES = 4096;
 // ======================================================================================== C ABI
 extern "C" {
 
+int y4_set_conv_mode(int mode) {
+    if (mode != 0 && mode != 1) return Y4_ERR_SHAPE;
+    g_conv_mode = mode;
+    return Y4_OK;
+}
+int y4_get_conv_mode(void) { return g_conv_mode; }
+
 static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
                          const float* scale, const float* shift, int act,
@@ -890,7 +1356,12 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
         g.out = dw;
     }
     int rc;
-    if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128>(g, st);
+    if (g_conv_mode == 1) {
+        if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, true>(g, st);
+        else if (g.tn == 128) rc = launch_wgrad<128, 64, true>(g, st);
+        else if (g.tj == 128) rc = launch_wgrad<64, 128, true>(g, st);
+        else rc = launch_wgrad<64, 64, true>(g, st);
+    } else if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128>(g, st);
     else if (g.tn == 128) rc = launch_wgrad<128, 64>(g, st);
     else if (g.tj == 128) rc = launch_wgrad<64, 128>(g, st);
     else rc = launch_wgrad<64, 64>(g, st);
