@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 FLOP_PER_IMG_608 = 402.63e9       # fwd + dgrad + wgrad conv flops per image @608
 
 
@@ -44,6 +45,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32'],
+                    help='conv arithmetic: exact 3-way bf16 split on the bf16 matrix cores (fp32-grade, default) '
+                         'or the fp32 MFMA fma chain')
     ap.add_argument('--conv-table', default=None, help='write a per-shape conv timing table to this file')
     return ap.parse_args()
 
@@ -165,6 +169,8 @@ def main():
     from yolov4_amd.yolo.model.yolov4 import YOLOv4
     from yolov4_amd.yolo.model.yololoss import YOLOLoss
 
+    import yolov4_amd
+    yolov4_amd.set_conv_mode(args.conv_mode)
     timer = ConvTimer()
     if not args.no_kernel_events:
         timer.wrap(ops)
@@ -227,6 +233,9 @@ def main():
             'config': {'workload': f'configs[2]: 1xMI355X training step, {S}x{S} bs={B}/GPU, fwd+bwd+YOLOLoss HIP kernels, '
                                    f'synthetic targets (SURVEY 8d config 3); random-init weights',
                        'global_batch': world * B, 'img_size': S, 'parallelism': f'dp{world}',
+                       'conv_arithmetic': ('bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, '
+                                           'fp32 accumulate (error <= the fp32-MFMA fma chain, see DESIGN.md)'
+                                           if args.conv_mode == 'bf16x3' else 'fp32 MFMA fma chain (v_mfma_f32_32x32x2_f32)'),
                        'loss': lossv, 'conv_tflops_whole_step': value / world * flop_img / 1e12},
         }
         if timer.rec:
@@ -238,7 +247,12 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS,
                                'traffic': pmc_traffic(dom),
-                               'kernel': kname,
+                               'kernel': kname + (' [bf16x3 variant]' if args.conv_mode == 'bf16x3' else ''),
+                               'mfma_pipe': ({'instr': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': 6 * summ[dom]['tflops'],
+                                              'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': 6 * summ[dom]['tflops'] / PEAK_BF16_MFMA_TFLOPS}
+                                             if args.conv_mode == 'bf16x3' else
+                                             {'instr': 'v_mfma_f32_32x32x2_f32', 'executed_tflops': summ[dom]['tflops'],
+                                              'peak': PEAK_F32_MFMA_TFLOPS, 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS}),
                                'avg_launch_ms': summ[dom]['seconds'] / summ[dom]['launches'] * 1e3,
                                'launches': summ[dom]['launches'],
                                'all_conv_kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['seconds'] / args.steps * 1e3, 2)}

@@ -48,9 +48,12 @@ int y4_version(void);
 int y4_device_count(void);
 
 /* Arithmetic of the conv implicit GEMMs (process-wide):
- *   0  v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain (default);
- *   1  "bf16x3": operands split exactly into 3 bf16 pieces, six bf16 MFMAs per product, fp32
- *      accumulate; dropped terms <= 2^-23 |a*b| -> fp32-grade results at 6/16 of the MFMA cost. */
+ *   1  "bf16x3" (default): every fp32 operand is split EXACTLY into three bf16 pieces (8+8+8
+ *      mantissa bits) while its tile is staged into LDS; a product is the six leading terms
+ *      a1b1+a1b2+a2b1+a1b3+a2b2+a3b1 on v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate).
+ *      Dropped terms <= 2^-23 |a*b|: measured error vs an fp64 convolution is at or below that of
+ *      mode 0 (rms 1.06e-6 vs 1.19e-6 of the output range at K = 4608), at 6/16 of the MFMA cost.
+ *   0  v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fma chain. */
 int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
 

@@ -57,8 +57,17 @@ CONV_CASES = [
 ]
 
 
+@pytest.fixture(params=['bf16x3', 'f32'])
+def conv_mode(request):
+    import yolov4_amd
+    old = yolov4_amd.get_conv_mode()
+    yolov4_amd.set_conv_mode(request.param)
+    yield request.param
+    yolov4_amd.set_conv_mode(old)
+
+
 @pytest.mark.parametrize('case', CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(dev, case):
+def test_conv_fwd_dgrad_wgrad(dev, case, conv_mode):
     from yolov4_amd import ops
     B, Cin, Cout, k, s, Hh, Ww = case
     x = recipe.randn((B, Cin, Hh, Ww), 1)
@@ -76,7 +85,7 @@ def test_conv_fwd_dgrad_wgrad(dev, case):
     close(dw, wr.grad)
 
 
-def test_conv_fused_epilogue(dev):
+def test_conv_fused_epilogue(dev, conv_mode):
     from yolov4_amd import ops
     B, Cin, Cout, k, s, Hh = 2, 64, 64, 3, 1, 11
     x = recipe.randn((B, Cin, Hh, Hh), 4)
@@ -115,7 +124,7 @@ def test_stem_kernels(dev):
         close(ops.conv_wgrad_raw(xin, cl(gy, dev), (32, 3, 3, 3), 3, 1), wr.grad)
 
 
-def test_conv_linearity_at_full_size(dev):
+def test_conv_linearity_at_full_size(dev, conv_mode):
     """Size-independent property at a BASELINE-size layer (128->128 3x3 @76x76, B=8):
     conv(a*x1 + x2) == a*conv(x1) + conv(x2) within fp32 rounding."""
     from yolov4_amd import ops
@@ -128,6 +137,25 @@ def test_conv_linearity_at_full_size(dev):
     # spot-check one output row against the CPU reference
     ref = F.conv2d(x1[:1], w.cpu(), None, 1, 1)
     close(y1[:1], ref)
+
+
+def test_conv_modes_accuracy_vs_fp64(dev):
+    """Both conv arithmetics against an fp64 convolution (K = 4608): the split-bf16 mode must be
+    fp32-grade, i.e. no worse than 1.5x the error of the exact fp32 fma chain."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    x = recipe.randn((2, 512, 19, 19), 41)
+    w = recipe.randn((256, 512, 3, 3), 42, 1.0 / np.sqrt(4608))
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    err = {}
+    old = yolov4_amd.get_conv_mode()
+    for mode in ('f32', 'bf16x3'):
+        yolov4_amd.set_conv_mode(mode)
+        y = ops.conv_fwd_raw(cl(x, dev), cl(w, dev), 3, 1).double().cpu()
+        err[mode] = float(((y - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt())
+    yolov4_amd.set_conv_mode(old)
+    assert err['f32'] < 5e-6 and err['bf16x3'] < 5e-6, err
+    assert err['bf16x3'] <= 1.5 * err['f32'], err
 
 
 # ------------------------------------------------------------------ ConvBNAct / blocks against the reference's goldens

@@ -626,7 +626,7 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
     return Y4_OK;
 }
 
-int g_conv_mode = 0;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs)
+int g_conv_mode = 1;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs; default)
 
 template <bool TR>
 int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
