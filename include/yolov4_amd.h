@@ -238,6 +238,14 @@ int y4_nms_f32(const float* boxes, const float* scores /* may be NULL */, long l
                int limit, int* keep_idx /* [R] */, int* n_keep /* [1] */,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- optimizer ("next" row 1)
+ * Fused Adam step over one dense parameter block; replaces torch.optim.Adam as the reference builds
+ * it (yolo/optim/optimizers/adam.py:14-15: betas (0.9, 0.999), eps 1e-8; both param groups of
+ * build.py:18-35 have weight_decay 0).  grad is multiplied by grad_scale first (1/accumulation). */
+int y4_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

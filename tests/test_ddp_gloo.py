@@ -44,6 +44,18 @@ def _worker(rank, world, port, out):
         ddp.finish_backward()
     if rank == 0:
         torch.save([p.grad.clone().contiguous() for p in net.parameters()], out)
+    # accumulation window of 2 micro-steps: exchange only on the second one; result = 2x the single-step grads
+    single = [p.grad.clone() for p in net.parameters()]
+    ddp.zero_grad()
+    for micro in range(2):
+        ddp.accumulating = micro == 0
+        if micro:
+            ddp.rearm()
+        loss = ((ddp(xs) - ys) ** 2).sum()
+        loss.backward()
+        ddp.finish_backward()
+    for a, p in zip(single, net.parameters()):
+        torch.testing.assert_close(p.grad, 2 * a, rtol=1e-5, atol=1e-6)
     dist.barrier()
     dist.destroy_process_group()
 

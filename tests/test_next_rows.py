@@ -1,0 +1,93 @@
+# -*- coding: utf-8 -*-
+"""SURVEY 8(f) "next" rows: optimizer factory / groups, LR schedule, checkpoint I/O (CPU side),
+fused Adam against torch.optim.Adam (GPU)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from yolov4_amd.yolo.model.yolov4 import YOLOv4
+from yolov4_amd.yolo.optim.lr_schedulers.build import adjust_learning_rate, build_lr_scheduler
+from yolov4_amd.yolo.optim.optimizers.build import FusedAdam, build_optimizer, filter_weight
+from yolov4_amd.yolo.util.checkpoint import load_checkpoint, save_checkpoint
+
+CFG = dict(recipe.FULL_CFG)
+CFG['OPTIMIZER'] = {'TYPE': 'ADAM', 'LR': '3e-4', 'NO_BIAS': True, 'NO_NORM': True}
+CFG['LR_SCHEDULER'] = {'TYPE': 'MultiStepLR', 'MILESTONES': [60, 90, 110], 'GAMMA': 0.1, 'IS_WARMUP': True,
+                       'WARMUP_EPOCH': 5, 'MULTIPLIER': 1.0}
+CFG['TRAIN'] = {'IMGSIZE': 608, 'MAX_EPOCHS': 120, 'ACCUMULATION_STEPS': 4}
+
+
+def test_param_groups_match_reference_rule():
+    m = YOLOv4(recipe.MODEL_CFG)
+    groups = filter_weight(CFG, m)
+    assert len(groups[0]['params']) == 110                 # every conv weight decays (config/yolov4_default.cfg:29-30)
+    assert len(groups[1]['params']) == 3 + 2 * 107         # 3 head biases + gamma/beta of 107 BatchNorms
+    assert groups[1]['weight_decay'] == 0.
+    opt = build_optimizer(CFG, m)
+    assert isinstance(opt, FusedAdam) and opt.defaults['lr'] == 3e-4 and opt.defaults['betas'] == (0.9, 0.999)
+    with pytest.raises(ValueError):
+        build_optimizer(dict(CFG, OPTIMIZER=dict(CFG['OPTIMIZER'], TYPE='LAMB')), m)
+
+
+def test_warmup_and_multistep_schedule():
+    lin = torch.nn.Linear(2, 2)
+    opt = FusedAdam(lin.parameters(), lr=3e-4)
+    len_epoch = 100
+    adjust_learning_rate(CFG, opt, epoch=0, step=0, len_epoch=len_epoch)
+    assert math.isclose(opt.param_groups[0]['lr'], 3e-4 * 1 / 500)
+    adjust_learning_rate(CFG, opt, epoch=2, step=49, len_epoch=len_epoch)
+    assert math.isclose(opt.param_groups[0]['lr'], 3e-4 * 250 / 500)
+    adjust_learning_rate(CFG, opt, epoch=5, step=0, len_epoch=len_epoch)
+    assert math.isclose(opt.param_groups[0]['lr'], 3e-4)
+    sch = build_lr_scheduler(CFG, opt)
+    assert list(sch.milestones) == [55, 85, 105]           # milestones shifted by the warm-up epochs
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    m = YOLOv4(recipe.MODEL_CFG)
+    sd = m.state_dict()
+    recipe.fill_state_dict_(sd, 5)
+    m.load_state_dict(sd)
+    state = {'epoch': 3, 'ap50': 0.1, 'ap50_95': 0.05, 'best_ap50': 0.1, 'best_ap50_95': 0.05,
+             'state_dict': {'module.' + k: v for k, v in m.state_dict().items()},      # as saved under DDP
+             'optimizer': {}, 'lr_scheduler': {}}
+    path = save_checkpoint(state, True, 'checkpoint_3.pth.tar', str(tmp_path))
+    assert os.path.isfile(os.path.join(str(tmp_path), 'model_best.pth.tar'))
+    raw = torch.load(path, map_location='cpu', weights_only=True)
+    w = raw['state_dict']['module.backbone.stage1.base.conv.weight']
+    assert w.is_contiguous() and tuple(w.shape) == (64, 32, 3, 3)                   # OIHW on the wire
+    m2 = YOLOv4(recipe.MODEL_CFG)
+    ck = load_checkpoint(m2, path)
+    assert ck['epoch'] == 3
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    assert m2.backbone.stage1.base.conv.weight.is_contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.gpu
+def test_fused_adam_matches_torch_adam():
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 32, 3, 3), (255,), (128,), (32, 3, 3, 3), (1024, 512, 1, 1)]
+    ref_p = [torch.randn(s, generator=g) for s in shapes]
+    hip_p = [torch.nn.Parameter((p.clone().contiguous(memory_format=torch.channels_last) if p.dim() == 4 else p.clone()).to(dev))
+             for p in ref_p]
+    ref_p = [torch.nn.Parameter(p) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=3e-4, betas=(0.9, 0.999), eps=1e-8)
+    hip = FusedAdam(hip_p, lr=3e-4)
+    for step in range(4):
+        for rp, hp in zip(ref_p, hip_p):
+            gr = torch.randn(rp.shape, generator=g) * (10.0 ** (step - 2))
+            rp.grad = gr.clone()
+            hp.grad = (gr.contiguous(memory_format=torch.channels_last) if gr.dim() == 4 else gr).to(dev)
+        if step == 2:
+            for o in (ref, hip):
+                for gp in o.param_groups:
+                    gp['lr'] = 1e-4
+        ref.step(); hip.step()
+    for rp, hp in zip(ref_p, hip_p):
+        np.testing.assert_allclose(hp.detach().cpu().numpy(), rp.detach().numpy(), rtol=2e-6, atol=2e-7)

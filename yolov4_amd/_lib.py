@@ -65,6 +65,7 @@ PROTOTYPES = {
     'y4_post_nms_f32': (I, [P, I, L, I, F, F, P, L, P, P, P, Z, P]),
     'y4_nms_workspace': (Z, [L]),
     'y4_nms_f32': (I, [P, P, L, F, I, P, P, P, Z, P]),
+    'y4_adam_step_f32': (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
 }
 
 _lib = None

@@ -46,6 +46,7 @@ class BucketedDDP(torch.nn.Module):
                 cur, n = [], 0
         if cur:
             self.buckets.append(self._make_bucket(cur))
+        self.accumulating = False     # set True for all but the last micro-step of an accumulation window
         self._hooks = []
         for b in self.buckets:
             for p in b.params:
@@ -85,7 +86,7 @@ class BucketedDDP(torch.nn.Module):
     def _make_hook(self, bucket):
         def hook(_param):
             bucket.pending -= 1
-            if bucket.pending == 0:
+            if bucket.pending == 0 and not self.accumulating:
                 self._launch(bucket)
         return hook
 
@@ -101,6 +102,12 @@ class BucketedDDP(torch.nn.Module):
     def zero_grad(self, set_to_none=False):
         for b in self.buckets:
             b.flat.zero_()
+        self.rearm()
+
+    def rearm(self):
+        """Before every backward of an accumulation window after the first (gradients keep accumulating
+        in the flat buckets; yolo/engine/build.py:56-69 steps every ACCUMULATION_STEPS micro-batches)."""
+        for b in self.buckets:
             b.pending, b.work, b.launched = len(b.params), None, False
 
     def forward(self, *a, **kw):
@@ -109,6 +116,8 @@ class BucketedDDP(torch.nn.Module):
     def finish_backward(self):
         """Call after loss.backward(): waits for the bucket exchanges (stream-wise: the current stream
         waits for RCCL's) and applies the 1/world average where the backend has no AVG."""
+        if self.accumulating:                 # local accumulation only: exchange happens on the last micro-step
+            return
         for b in self.buckets:
             if not b.launched:
                 self._launch(b)               # parameters that received no gradient this step
