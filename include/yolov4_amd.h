@@ -56,6 +56,12 @@ int y4_device_count(void);
  *   0  v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fma chain. */
 int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
+/* Scratch arena for library temporaries whose size depends only on the layer (the pre-split filter
+ * planes of mode 1: 6 B per filter element, <= 28.3 MB for YOLOv4).  Caller-owned device memory, used
+ * in stream order by every conv forward issued afterwards (one stream at a time per process);
+ * stays registered until replaced or reset with (NULL, 0).  Forward convs in mode 1 return
+ * Y4_ERR_WORKSPACE when it is missing or too small. */
+int y4_set_workspace(void* ptr, size_t bytes);
 
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d inside ConvBNAct.forward, darknet/darknet.py:31-36,53-54

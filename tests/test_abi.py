@@ -46,7 +46,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_workspace_queries_run_on_host():
     L = yolov4_amd.lib()
-    assert L.y4_conv2d_dgrad_workspace(128, 255, 3) == 128 * 9 * 256 * 4
+    assert L.y4_conv2d_dgrad_workspace(128, 255, 3) == 128 * 9 * 256 * 6
     assert L.y4_bn_workspace(1000, 64) >= 2 * 64 * 8
     assert L.y4_conv2d_wgrad_workspace(64, 76, 76, 128, 128, 3, 1) > 0
     assert L.y4_yolo_loss_workspace(4, 76, 3, 60, 80) > 4 * 3 * 76 * 76 * 4

@@ -10,7 +10,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libyolov4_amd.so')
+LIB_PATH = os.environ.get('Y4_LIB_PATH') or os.path.join(_HERE, 'lib', 'libyolov4_amd.so')   # override: kernel experiments
 
 ACT_IDS = {'linear': 0, 'leaky_relu': 1, 'mish': 2, 'relu': 3}
 
@@ -29,6 +29,7 @@ PROTOTYPES = {
     'y4_device_count': (I, []),
     'y4_set_conv_mode': (I, [I]),
     'y4_get_conv_mode': (I, []),
+    'y4_set_workspace': (I, [P, Z]),
     'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
     'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P]),

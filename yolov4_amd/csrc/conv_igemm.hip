@@ -39,6 +39,7 @@ struct ConvGeom {
     int cls_h[2], cls_w[2];       // class extents: (Hd + 1 - ph) / 2, (Wd + 1 - pw) / 2
     int cls_slot0[5];             // classed launch: per-XCD slot ranges (each XCD gets 1/8 of EVERY class)
     unsigned src_bytes, wt_bytes; // extents for the buffer descriptors (< 4 GiB, checked on the host)
+    const unsigned short* wt_planes;   // bf16x3 mode: filter pre-split into 3 bf16 planes [3][N][K] (library scratch)
 };
 
 // TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
@@ -327,7 +328,8 @@ template <int BM, int BN, int WM, int WN, bool TRANSPOSED>
 __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     constexpr int BK = 32;
     constexpr int PITCH_B = 80;                        // bytes per LDS row (32 bf16 + 16 B pad)
-    constexpr int PA = BM / 32, PB = BN / 32;
+    constexpr int PA = BM / 32;
+    constexpr int NB = (BN * 4 + 255) / 256;           // 16-B chunks of the B tile per thread and plane
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4, "4 waves");
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     const int lrow = tid >> 3, kc = tid & 7;
 
     const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, g.src_bytes);
-    const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt, g.wt_bytes);
+    const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt_planes, g.wt_bytes);     // 3 planes of N*K bf16
     const unsigned OOB = 0xffffffffu;
     unsigned a_base[PA];
     int a_h[PA], a_w[PA];
@@ -396,17 +398,27 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
         if (!TRANSPOSED) { a_h[p] = hd * g.stride - g.pad; a_w[p] = wd * g.stride - g.pad; }
         else { a_h[p] = hd + g.pad; a_w[p] = wd + g.pad; }
     }
-    unsigned b_off[PB];
+    // B chunks: slot = tid + 256*i -> (row = slot/4, 16-B chunk = slot%4) of each plane
+    unsigned b_off[NB];
+    int b_lds[NB];
+    const unsigned plane_bytes = (unsigned)g.N * (unsigned)g.K * 2u;
 #pragma unroll
-    for (int p = 0; p < PB; ++p) {
-        const int n = n0 + p * 32 + lrow;
-        b_off[p] = n < g.N ? (unsigned)n * (unsigned)g.K * 4u + kc * 16u : OOB;
+    for (int i = 0; i < NB; ++i) {
+        const int slot = tid + 256 * i;
+        const int row = slot >> 2, ch = slot & 3;
+        const bool ok = row < BN && (n0 + row) < g.N;
+        b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 2u + ch * 16u : OOB;
+        b_lds[i] = row < BN ? row * PITCH_B + ch * 16 : -1;
     }
 
-    f32x4 ra[PA], rb[PB];
+    f32x4 ra[PA];
+    u32x4 rb[NB][3];
     const int CC = g.Cs / BK;
     int r = r0, q = q0, cc = 0;
-    auto load_tile = [&]() {
+    // per-tap A offsets: the halo test and the pixel address are recomputed only when the filter tap
+    // changes (every CC K-tiles); inside a tap the K position is a scalar offset of the buffer load
+    unsigned a_off[PA];
+    auto tap_setup = [&]() {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             int hi, wi;
@@ -420,13 +432,20 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
                 if (g.stride == 2) { hi = th >> 1; wi = tw >> 1; }
                 ok = ok && th >= 0 && tw >= 0 && hi < g.Hs && wi < g.Ws;
             }
-            const unsigned off = a_base[p] + (unsigned)(hi * g.Ws + wi) * pix_bytes;
-            ra[p] = y4_buf_load4(src_rsrc, ok ? off : OOB, (unsigned)(cc * BK) * 4u);
+            a_off[p] = ok ? a_base[p] + (unsigned)(hi * g.Ws + wi) * pix_bytes : OOB;
         }
-        const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 4u);
+    };
+    tap_setup();
+    auto load_tile = [&]() {
 #pragma unroll
-        for (int p = 0; p < PB; ++p) rb[p] = y4_buf_load4(wt_rsrc, b_off[p], koff);
-        if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } }
+        for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
+        const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 2u);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)(koff + pl * plane_bytes), 0);
+        if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } tap_setup(); }
     };
     int st_cc = 0;
     auto store_tile = [&]() {
@@ -446,14 +465,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
             *reinterpret_cast<u32x2*>(d + 2 * BM * PITCH_B) = p3;
         }
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            u32x2 p1, p2, p3;
-            split3x4(rb[p], p1, p2, p3);
-            unsigned char* d = Bs + (p * 32 + lrow) * PITCH_B + kc * 8;
-            *reinterpret_cast<u32x2*>(d) = p1;
-            *reinterpret_cast<u32x2*>(d + BN * PITCH_B) = p2;
-            *reinterpret_cast<u32x2*>(d + 2 * BN * PITCH_B) = p3;
-        }
+        for (int i = 0; i < NB; ++i)
+            if (b_lds[i] >= 0) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<u32x4*>(Bs + pl * BN * PITCH_B + b_lds[i]) = rb[i][pl];
+            }
         if (++st_cc == CC) st_cc = 0;
     };
 
@@ -560,6 +577,20 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     }
 }
 
+// fp32 filter [N][K] -> three bf16 planes [3][N][K] (exact truncation split, as split3x4)
+__global__ void split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = w[i];
+        const unsigned h1 = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(h1 & 0xffff0000u);
+        const unsigned h2 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(h2 & 0xffff0000u);
+        planes[i] = (unsigned short)(h1 >> 16);
+        planes[n + i] = (unsigned short)(h2 >> 16);
+        planes[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+}
+
 // [Cout][k][k][Cin] -> [Cin][k][k][Cout4] (zero padded to a multiple of 32 output channels)
 __global__ void transpose_filter_kernel(const float* __restrict__ w, float* __restrict__ wt,
                                         int Cout, int Cin, int kk, int Cout_pad) {
@@ -573,6 +604,31 @@ __global__ void transpose_filter_kernel(const float* __restrict__ w, float* __re
         wt[i] = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
     }
 }
+
+// [Cout][k][k][Cin] fp32 -> 3 bf16 planes of [Cin][k][k][Cout_pad] (dgrad filter for the bf16x3 kernels)
+__global__ void transpose_split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                              int Cout, int Cin, int kk, int Cout_pad) {
+    const long long total = (long long)Cin * kk * Cout_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Cout_pad);
+        const long long t = i / Cout_pad;
+        const int tap = (int)(t % kk);
+        const int c = (int)(t / kk);
+        const float v = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
+        const unsigned h1 = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(h1 & 0xffff0000u);
+        const unsigned h2 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(h2 & 0xffff0000u);
+        planes[i] = (unsigned short)(h1 >> 16);
+        planes[total + i] = (unsigned short)(h2 >> 16);
+        planes[2 * total + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+}
+
+// process-wide scratch arena for library temporaries (pre-split filters); set by y4_set_workspace
+void* g_scratch = nullptr;
+size_t g_scratch_bytes = 0;
 
 template <int BM, int BN, int WM, int WN, bool TR, int BKT = 32, bool SPLIT = false>
 int launch_gather(const ConvGeom& g0, hipStream_t st) {
@@ -599,6 +655,10 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
         const unsigned long long wb = (unsigned long long)g.N * g.K * 4ull;
         if (sb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;   // 32-bit buffer offsets
         g.src_bytes = (unsigned)sb; g.wt_bytes = (unsigned)wb;
+        if (SPLIT) {
+            if (!g.wt_planes) return Y4_ERR_WORKSPACE;
+            g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 6ull);
+        }
     }
     const size_t smem = SPLIT ? 3ull * (BM + BN) * 80 + BM * sizeof(int)
                               : 2ull * (BM + BN) * (BKT + 4) * sizeof(float) + BM * sizeof(int);
@@ -1231,6 +1291,13 @@ int y4_set_conv_mode(int mode) {
 }
 int y4_get_conv_mode(void) { return g_conv_mode; }
 
+int y4_set_workspace(void* ptr, size_t bytes) {
+    if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15)) return Y4_ERR_SHAPE;
+    g_scratch = ptr;
+    g_scratch_bytes = ptr ? bytes : 0;
+    return Y4_OK;
+}
+
 static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
                          const float* scale, const float* shift, int act,
@@ -1252,6 +1319,15 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
     const long long M = (long long)B * g.Hd * g.Wd;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cin; g.act = act;
+    if (g_conv_mode == 1) {
+        const long long nw = (long long)Cout * g.K;
+        if (!g_scratch || g_scratch_bytes < (size_t)nw * 6) return Y4_ERR_WORKSPACE;   // y4_set_workspace() first
+        unsigned short* planes = static_cast<unsigned short*>(g_scratch);
+        const int blocks = (int)((nw + 255) / 256 > 4096 ? 4096 : (nw + 255) / 256);
+        hipLaunchKernelGGL(split_filter_kernel, dim3(blocks), dim3(256), 0, y4_stream(stream), w, planes, nw);
+        Y4_CHECK_LAUNCH();
+        g.wt_planes = planes;
+    }
     return dispatch_gather<false>(g, y4_stream(stream), bm_used);
 }
 
@@ -1288,7 +1364,7 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
 
 size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
     const size_t cp = (size_t)((Cout + 31) / 32) * 32;
-    return (size_t)Cin * k * k * cp * sizeof(float);
+    return (size_t)Cin * k * k * cp * 6;       // fp32 transposed filter (4 B) or 3 bf16 planes (6 B) per element
 }
 
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
@@ -1306,11 +1382,16 @@ int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, in
     float* wt = static_cast<float*>(workspace);
     const long long total = (long long)Cin * k * k * Cout_pad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(transpose_filter_kernel, dim3(blocks), dim3(256), 0, st, w, wt, Cout, Cin, k * k, Cout_pad);
+    if (g_conv_mode == 1)
+        hipLaunchKernelGGL(transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w,
+                           static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad);
+    else
+        hipLaunchKernelGGL(transpose_filter_kernel, dim3(blocks), dim3(256), 0, st, w, wt, Cout, Cin, k * k, Cout_pad);
     Y4_CHECK_LAUNCH();
     const int pad = (k - 1) / 2;
     ConvGeom g{};
     g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = nullptr;
+    g.wt_planes = static_cast<const unsigned short*>(workspace);
     g.lds_ = lddy; g.ldd = lddx; g.ldr = 0;
     g.B = B;
     g.Hs = (H + 2 * pad - k) / stride + 1;

@@ -94,6 +94,22 @@ def krsc(w):
     return w if same else w.contiguous(memory_format=CL)
 
 
+_SCRATCH = {}
+
+
+def ensure_scratch(device, nbytes=64 << 20):
+    """Register the library's scratch arena (pre-split filter planes) once per device."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _SCRATCH[key] = buf
+    if _SCRATCH.get('active') != key or _SCRATCH.get('active_ptr') != buf.data_ptr():
+        check(lib().y4_set_workspace(_ptr(buf), buf.numel()), 'set_workspace')
+        _SCRATCH['active'] = key
+        _SCRATCH['active_ptr'] = buf.data_ptr()
+
+
 def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
 
@@ -113,6 +129,7 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
         out = empty_nhwc(B, Cout, Ho, Wo, x.device, pad_to=out_pad)
     ldy = nhwc_pitch(out)
     w = krsc(w)
+    ensure_scratch(x.device)
     if Cin == 3:
         if k != 3 or s != 1 or residual is not None:
             raise Y4Error('Cin=3 is supported for the 3x3/s1 stem only')
@@ -139,6 +156,7 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     y = empty_nhwc(B, Cout, Ho, Wo, x.device)
     ldy = nhwc_pitch(y)
     w = krsc(w)
+    ensure_scratch(x.device)
     pbytes = L.y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, s)
     part = _ws(pbytes, x.device)
     if Cin == 3:
