@@ -126,12 +126,20 @@ def pmc_traffic(kind):
     if not os.path.isfile(path):
         return None
     tab = json.load(open(path))
-    want = {'conv_fwd': 'conv_gather_mfma_f32<128, 128, 2, 2, false', 'conv_dgrad': 'conv_gather_mfma_f32<128, 128, 2, 2, true',
-            'conv_wgrad': 'conv_wgrad_mfma_f32<128, 128>'}[kind]
+    fam = {'conv_fwd': ('conv_gather_', '<128, 128, 2, 2, false'), 'conv_dgrad': ('conv_gather_', '<128, 128, 2, 2, true'),
+           'conv_wgrad': ('conv_wgrad_', '<128, 128>')}[kind]
+    mode = 'bf16x3' if args_conv_mode() == 'bf16x3' else 'mfma_f32'
     for k, v in tab.items():
-        if want in k:
+        if fam[0] + mode in k and fam[1] in k:
             return v['hbm_bytes_per_launch_corrected']
     return None
+
+
+_ARGS = {}
+
+
+def args_conv_mode():
+    return _ARGS.get('conv_mode', 'bf16x3')
 
 
 def cpu_baseline(size, batch):
@@ -171,6 +179,7 @@ def main():
 
     import yolov4_amd
     yolov4_amd.set_conv_mode(args.conv_mode)
+    _ARGS['conv_mode'] = args.conv_mode
     timer = ConvTimer()
     if not args.no_kernel_events:
         timer.wrap(ops)
@@ -241,13 +250,14 @@ def main():
         if timer.rec:
             summ = timer.summary()
             dom = max(summ, key=lambda k: summ[k]['seconds'])
-            kname = {'conv_fwd': 'conv_gather_mfma_f32<..,false> (forward implicit GEMM, BN-stat epilogue + fold kernels included)',
-                     'conv_dgrad': 'conv_gather_mfma_f32<..,true> (dgrad implicit GEMM, incl. filter transpose)',
-                     'conv_wgrad': 'conv_wgrad_mfma_f32 (+ slab reduce)'}[dom]
+            kk = 'bf16x3' if args.conv_mode == 'bf16x3' else 'mfma_f32'
+            kname = {'conv_fwd': f'conv_gather_{kk}<..,false> (forward implicit GEMM; filter split, BN-stat fold kernels included)',
+                     'conv_dgrad': f'conv_gather_{kk}<..,true> (dgrad implicit GEMM; filter transpose/split included)',
+                     'conv_wgrad': f'conv_wgrad_{kk} (+ slab reduce)'}[dom]
             out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS,
                                'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS,
                                'traffic': pmc_traffic(dom),
-                               'kernel': kname + (' [bf16x3 variant]' if args.conv_mode == 'bf16x3' else ''),
+                               'kernel': kname,
                                'mfma_pipe': ({'instr': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': 6 * summ[dom]['tflops'],
                                               'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': 6 * summ[dom]['tflops'] / PEAK_BF16_MFMA_TFLOPS}
                                              if args.conv_mode == 'bf16x3' else

@@ -296,6 +296,38 @@ def test_yololoss_golden(dev, golden):
         close(outs[l]['output'], g[f'mutated_output{l}'], 1e-6, 1e-6, scale=False)   # the in-place side effect
 
 
+def test_head_and_loss_full_size_vs_oracle(dev):
+    """BASELINE-size heads (608 px: F = 76/38/19, B = 4, synthetic labels per SURVEY 8d incl. an empty image):
+    decode + target assignment + loss + gradient against the oracle on the same logits; masks bit-exact."""
+    from yolov4_amd.yolo.model.yololayer import YOLOLayer
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    B = 4
+    labels = recipe.synth_labels(B, 608, 91, counts=[60, 0, 17, 1])
+    crit = YOLOLoss(CFG, ignore_thresh=0.7, device=dev, mutate_outputs=False)
+    xs, outs, logits = [], [], []
+    for l, Fs in enumerate((76, 38, 19)):
+        lg = recipe.synth_head_logits(B, Fs, 700 + l)
+        logits.append(lg.numpy())
+        x = lg.to(dev).requires_grad_(True)
+        r = YOLOLayer(CFG, l, device=dev).train()(x)
+        xs.append(x); outs.append(r)
+        o_ref, p_ref = H.yolo_decode(lg.numpy(), l, CFG, True)
+        close(r['output'], o_ref, 1e-6, 1e-6, scale=False)
+        close(r['pred'], p_ref, 1e-5, 1e-5)
+        # masks from the oracle on the HIP path's own decode (same inputs -> must be identical)
+        _, obj_ref, tm_ref, _ = H.build_target(r['output'].detach().cpu().numpy(), r['pred'].detach().cpu().numpy(), l,
+                                               labels.numpy(), CFG, 0.7)
+        _, obj, tm, _ = crit.build_target(r['output'], r['pred'], l, labels)
+        assert np.array_equal(obj.cpu().numpy(), obj_ref)
+        assert np.array_equal(tm.cpu().numpy(), tm_ref)
+    loss = crit(outs, {'padded_labels': labels})
+    ref_loss, ref_grads = H.yolo_loss(logits, labels.numpy(), CFG, 0.7)
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-4 * abs(ref_loss)
+    loss.backward()
+    for l in range(3):
+        close(xs[l].grad, ref_grads[l], 1e-5, 1e-4)
+
+
 def test_postprocess_golden(dev, golden):
     from yolov4_amd.yolo.util.utils import postprocess
     g = golden('postprocess')
