@@ -32,7 +32,9 @@ class BucketedDDP(torch.nn.Module):
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         self.backend = dist.get_backend(self.pg) if dist.is_initialized() else None
-        if broadcast and self.world > 1:
+        # collectives run whenever a process group exists (also at world_size 1: exercises the RCCL path)
+        self.use_dist = dist.is_initialized()
+        if broadcast and self.use_dist:
             self._broadcast_state()
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()                       # backward produces gradients roughly in this order
@@ -91,7 +93,7 @@ class BucketedDDP(torch.nn.Module):
         return hook
 
     def _launch(self, b):
-        if b.launched or self.world == 1:
+        if b.launched or not self.use_dist:
             b.launched = True
             return
         op = dist.ReduceOp.AVG if self.backend == 'nccl' else dist.ReduceOp.SUM
