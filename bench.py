@@ -45,7 +45,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--no-kernel-events', action='store_true')
-    ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32'],
+    ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32', 'bf16'],
                     help='conv arithmetic: exact 3-way bf16 split on the bf16 matrix cores (fp32-grade, default) '
                          'or the fp32 MFMA fma chain')
     ap.add_argument('--conv-table', default=None, help='write a per-shape conv timing table to this file')
@@ -128,7 +128,7 @@ def pmc_traffic(kind):
     tab = json.load(open(path))
     fam = {'conv_fwd': ('conv_gather_', '<128, 128, 2, 2, false'), 'conv_dgrad': ('conv_gather_', '<128, 128, 2, 2, true'),
            'conv_wgrad': ('conv_wgrad_', '<128, 128>')}[kind]
-    mode = 'bf16x3' if args_conv_mode() == 'bf16x3' else 'mfma_f32'
+    mode = 'mfma_f32' if args_conv_mode() == 'f32' else 'bf16x3'
     for k, v in tab.items():
         if fam[0] + mode in k and fam[1] in k:
             return v['hbm_bytes_per_launch_corrected']
@@ -242,29 +242,35 @@ def main():
             'metric': 'images/sec fwd+bwd @608x608 bs=64 per GPU (YOLOv4 training step: forward + YOLOLoss + backward)',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'bf16' if args.conv_mode == 'bf16' else 'f32', 'data': 'synthetic',
             'config': {'workload': f'configs[2]: 1xMI355X training step, {S}x{S} bs={B}/GPU, fwd+bwd+YOLOLoss HIP kernels, '
                                    f'synthetic targets (SURVEY 8d config 3); random-init weights',
                        'global_batch': world * B, 'img_size': S, 'parallelism': f'dp{world}',
                        'conv_arithmetic': ('bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, '
                                            'fp32 accumulate (error <= the fp32-MFMA fma chain, see DESIGN.md)'
-                                           if args.conv_mode == 'bf16x3' else 'fp32 MFMA fma chain (v_mfma_f32_32x32x2_f32)'),
+                                           if args.conv_mode == 'bf16x3' else
+                                           'plain bf16 MFMA operands (RN), fp32 accumulate; fp32 BN/loss/NMS (config 5, mixed precision)'
+                                           if args.conv_mode == 'bf16' else 'fp32 MFMA fma chain (v_mfma_f32_32x32x2_f32)'),
                        'loss': lossv, 'conv_tflops_whole_step': value / world * flop_img / 1e12},
         }
         if timer.rec:
             summ = timer.summary()
             dom = max(summ, key=lambda k: summ[k]['seconds'])
-            kk = 'bf16x3' if args.conv_mode == 'bf16x3' else 'mfma_f32'
+            kk = 'mfma_f32' if args.conv_mode == 'f32' else 'bf16x3'
             kname = {'conv_fwd': f'conv_gather_{kk}<..,false> (forward implicit GEMM; filter split, BN-stat fold kernels included)',
                      'conv_dgrad': f'conv_gather_{kk}<..,true> (dgrad implicit GEMM; filter transpose/split included)',
                      'conv_wgrad': f'conv_wgrad_{kk} (+ slab reduce)'}[dom]
-            out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS,
-                               'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS,
+            peak = PEAK_BF16_MFMA_TFLOPS if args.conv_mode == 'bf16' else PEAK_F32_MFMA_TFLOPS
+            out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': peak,
+                               'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / peak,
                                'traffic': pmc_traffic(dom),
                                'kernel': kname,
                                'mfma_pipe': ({'instr': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': 6 * summ[dom]['tflops'],
                                               'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': 6 * summ[dom]['tflops'] / PEAK_BF16_MFMA_TFLOPS}
                                              if args.conv_mode == 'bf16x3' else
+                                             {'instr': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': summ[dom]['tflops'],
+                                              'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': summ[dom]['tflops'] / PEAK_BF16_MFMA_TFLOPS}
+                                             if args.conv_mode == 'bf16' else
                                              {'instr': 'v_mfma_f32_32x32x2_f32', 'executed_tflops': summ[dom]['tflops'],
                                               'peak': PEAK_F32_MFMA_TFLOPS, 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS}),
                                'avg_launch_ms': summ[dom]['seconds'] / summ[dom]['launches'] * 1e3,

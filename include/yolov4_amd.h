@@ -53,7 +53,10 @@ int y4_device_count(void);
  *      a1b1+a1b2+a2b1+a1b3+a2b2+a3b1 on v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate).
  *      Dropped terms <= 2^-23 |a*b|: measured error vs an fp64 convolution is at or below that of
  *      mode 0 (rms 1.06e-6 vs 1.19e-6 of the output range at K = 4608), at 6/16 of the MFMA cost.
- *   0  v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fma chain. */
+ *   0  v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fma chain.
+ *   2  plain bf16: operands rounded (RN) to bf16 while staged, one bf16 MFMA per product, fp32
+ *      accumulate; activations / gradients / BN / loss / NMS stay fp32 (BASELINE config 5, mixed
+ *      precision -- NOT fp32-grade: ~3 significant digits per product). */
 int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
 /* Scratch arena for library temporaries whose size depends only on the layer (the pre-split filter

@@ -139,6 +139,27 @@ def test_conv_linearity_at_full_size(dev, conv_mode):
     close(y1[:1], ref)
 
 
+def test_conv_plain_bf16_mode(dev):
+    """BASELINE config 5 arithmetic (bf16 MFMA operands, fp32 accumulate): mixed precision, so only a loose
+    bound holds against the fp32 reference -- 2^-8 relative per operand -> ~1e-2 of the output range."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    old = yolov4_amd.get_conv_mode()
+    yolov4_amd.set_conv_mode('bf16')
+    try:
+        for (B, Cin, Cout, k, s, Hh) in [(2, 128, 128, 3, 1, 12), (2, 64, 255, 1, 1, 9), (2, 64, 128, 3, 2, 13)]:
+            x = recipe.randn((B, Cin, Hh, Hh), 1); w = recipe.randn((Cout, Cin, k, k), 2, 1.0 / np.sqrt(Cin * k * k))
+            xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+            yr = F.conv2d(xr, wr, None, s, (k - 1) // 2)
+            gy = recipe.randn(tuple(yr.shape), 3)
+            yr.backward(gy)
+            close(ops.conv_fwd_raw(cl(x, dev), cl(w, dev), k, s), yr, 2e-2, 2e-2)
+            close(ops.conv_dgrad_raw(cl(gy, dev), cl(w, dev), (B, Cin, Hh, Hh), k, s), xr.grad, 2e-2, 2e-2)
+            close(ops.conv_wgrad_raw(cl(x, dev), cl(gy, dev), (Cout, Cin, k, k), k, s), wr.grad, 2e-2, 2e-2)
+    finally:
+        yolov4_amd.set_conv_mode(old)
+
+
 def test_conv_modes_accuracy_vs_fp64(dev):
     """Both conv arithmetics against an fp64 convolution (K = 4608): the split-bf16 mode must be
     fp32-grade, i.e. no worse than 1.5x the error of the exact fp32 fma chain."""

@@ -309,6 +309,18 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // pack the upper halves (= truncated bf16) of two fp32 words: result = {hi16(x1), hi16(x0)}
 __device__ __forceinline__ unsigned pack_hi16(unsigned x1, unsigned x0) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); }
 
+// round-to-nearest-even bf16 of 4 floats, packed (plain-bf16 mode: one plane, one MFMA per product)
+__device__ __forceinline__ unsigned rn_bf16_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return u + 0x7fffu + ((u >> 16) & 1u);            // upper half = RN bf16 (NaN payloads aside)
+}
+__device__ __forceinline__ u32x2 round1x4(const f32x4 v) {
+    u32x2 p;
+    p[0] = pack_hi16(rn_bf16_bits(v[1]), rn_bf16_bits(v[0]));
+    p[1] = pack_hi16(rn_bf16_bits(v[3]), rn_bf16_bits(v[2]));
+    return p;
+}
+
 __device__ __forceinline__ void split3x4(const f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
     unsigned h1[4], h2[4], h3[4];
 #pragma unroll
@@ -324,7 +336,7 @@ __device__ __forceinline__ void split3x4(const f32x4 v, u32x2& p1, u32x2& p2, u3
     p3[0] = pack_hi16(h3[1], h3[0]); p3[1] = pack_hi16(h3[3], h3[2]);
 }
 
-template <int BM, int BN, int WM, int WN, bool TRANSPOSED>
+template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int NP = 3>
 __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     constexpr int BK = 32;
     constexpr int PITCH_B = 80;                        // bytes per LDS row (32 bf16 + 16 B pad)
@@ -334,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     constexpr int TM = WTM / 32, TN = WTN / 32;
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* As = smem_b;                        // [3][BM][80 B]
-    unsigned char* Bs = smem_b + 3 * BM * PITCH_B;     // [3][BN][80 B]
-    int* row_m = reinterpret_cast<int*>(smem_b + 3 * (BM + BN) * PITCH_B);
+    unsigned char* As = smem_b;                        // [NP][BM][80 B]
+    unsigned char* Bs = smem_b + NP * BM * PITCH_B;    // [NP][BN][80 B]
+    int* row_m = reinterpret_cast<int*>(smem_b + NP * (BM + BN) * PITCH_B);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     }
 
     f32x4 ra[PA];
-    u32x4 rb[NB][3];
+    u32x4 rb[NB][NP];
     const int CC = g.Cs / BK;
     int r = r0, q = q0, cc = 0;
     // per-tap A offsets: the halo test and the pixel address are recomputed only when the filter tap
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
 #pragma unroll
         for (int i = 0; i < NB; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < NP; ++pl)
                 rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)(koff + pl * plane_bytes), 0);
         if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } tap_setup(); }
     };
@@ -457,18 +469,22 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
                 for (int e = 0; e < 4; ++e)
                     if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
             }
-            u32x2 p1, p2, p3;
-            split3x4(v, p1, p2, p3);
             unsigned char* d = As + (p * 32 + lrow) * PITCH_B + kc * 8;
-            *reinterpret_cast<u32x2*>(d) = p1;
-            *reinterpret_cast<u32x2*>(d + BM * PITCH_B) = p2;
-            *reinterpret_cast<u32x2*>(d + 2 * BM * PITCH_B) = p3;
+            if constexpr (NP == 3) {
+                u32x2 p1, p2, p3;
+                split3x4(v, p1, p2, p3);
+                *reinterpret_cast<u32x2*>(d) = p1;
+                *reinterpret_cast<u32x2*>(d + BM * PITCH_B) = p2;
+                *reinterpret_cast<u32x2*>(d + 2 * BM * PITCH_B) = p3;
+            } else {
+                *reinterpret_cast<u32x2*>(d) = round1x4(v);
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             if (b_lds[i] >= 0) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     *reinterpret_cast<u32x4*>(Bs + pl * BN * PITCH_B + b_lds[i]) = rb[i][pl];
             }
         if (++st_cc == CC) st_cc = 0;
@@ -495,27 +511,29 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
         if (kt + 1 < KT) load_tile();                  // next tile's loads fly under this tile's MFMAs
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 fa[TM][3], fb[TN][3];
+            bf16x8 fa[TM][NP], fb[TN][NP];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * BM * PITCH_B + i * 32 * PITCH_B + ks * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NP; ++pl)
                     fb[j][pl] = *reinterpret_cast<const bf16x8*>(b_frag + pl * BN * PITCH_B + j * 32 * PITCH_B + ks * 32);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    f32x16 c = acc[i][j];                 // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                    f32x16 c = acc[i][j];
+                    if constexpr (NP == 3) {                  // small terms first
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                    }
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
                     acc[i][j] = c;
                 }
@@ -578,9 +596,10 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
 }
 
 // fp32 filter [N][K] -> three bf16 planes [3][N][K] (exact truncation split, as split3x4)
-__global__ void split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, long long n) {
+__global__ void split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes, long long n, int np) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float v = w[i];
+        if (np == 1) { planes[i] = (unsigned short)(rn_bf16_bits(v) >> 16); continue; }
         const unsigned h1 = __float_as_uint(v);
         const float r1 = v - __uint_as_float(h1 & 0xffff0000u);
         const unsigned h2 = __float_as_uint(r1);
@@ -607,7 +626,7 @@ __global__ void transpose_filter_kernel(const float* __restrict__ w, float* __re
 
 // [Cout][k][k][Cin] fp32 -> 3 bf16 planes of [Cin][k][k][Cout_pad] (dgrad filter for the bf16x3 kernels)
 __global__ void transpose_split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
-                                              int Cout, int Cin, int kk, int Cout_pad) {
+                                              int Cout, int Cin, int kk, int Cout_pad, int np) {
     const long long total = (long long)Cin * kk * Cout_pad;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -616,6 +635,7 @@ __global__ void transpose_split_filter_kernel(const float* __restrict__ w, unsig
         const int tap = (int)(t % kk);
         const int c = (int)(t / kk);
         const float v = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
+        if (np == 1) { planes[i] = (unsigned short)(rn_bf16_bits(v) >> 16); continue; }
         const unsigned h1 = __float_as_uint(v);
         const float r1 = v - __uint_as_float(h1 & 0xffff0000u);
         const unsigned h2 = __float_as_uint(r1);
@@ -630,8 +650,9 @@ __global__ void transpose_split_filter_kernel(const float* __restrict__ w, unsig
 void* g_scratch = nullptr;
 size_t g_scratch_bytes = 0;
 
-template <int BM, int BN, int WM, int WN, bool TR, int BKT = 32, bool SPLIT = false>
+template <int BM, int BN, int WM, int WN, bool TR, int BKT = 32, int NP = 0>
 int launch_gather(const ConvGeom& g0, hipStream_t st) {
+    constexpr bool SPLIT = NP > 0;
     ConvGeom g = g0;
     if (TR && g.stride == 2) {
         int t = 0;
@@ -657,13 +678,13 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
         g.src_bytes = (unsigned)sb; g.wt_bytes = (unsigned)wb;
         if (SPLIT) {
             if (!g.wt_planes) return Y4_ERR_WORKSPACE;
-            g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 6ull);
+            g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * NP);
         }
     }
-    const size_t smem = SPLIT ? 3ull * (BM + BN) * 80 + BM * sizeof(int)
+    const size_t smem = SPLIT ? (size_t)NP * (BM + BN) * 80 + BM * sizeof(int)
                               : 2ull * (BM + BN) * (BKT + 4) * sizeof(float) + BM * sizeof(int);
     void (*kern)(const ConvGeom);
-    if constexpr (SPLIT) kern = conv_gather_bf16x3<BM, BN, WM, WN, TR>;
+    if constexpr (SPLIT) kern = conv_gather_bf16x3<BM, BN, WM, WN, TR, (NP > 0 ? NP : 3)>;
     else kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR, BKT>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -686,12 +707,14 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
     return Y4_OK;
 }
 
-int g_conv_mode = 1;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs; default)
+int g_conv_mode = 1;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs; default),
+                              // 2: plain bf16 operands (RN), fp32 accumulate -- mixed precision, BASELINE config 5
 
 template <bool TR>
 int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
     if (bm_used) *bm_used = 128;
-    if (g_conv_mode == 1) {
+    if (g_conv_mode == 1 || g_conv_mode == 2) {
+        const bool one = g_conv_mode == 2;
         if (g.N > 64) {
             const long long nt = (g.N + 127) / 128;
             const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
@@ -699,12 +722,12 @@ int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
             const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.10;
             if (c64 < c128 && !(TR && g.stride == 2)) {
                 if (bm_used) *bm_used = 64;
-                return launch_gather<64, 128, 2, 2, TR, 32, true>(g, st);
+                return one ? launch_gather<64, 128, 2, 2, TR, 32, 1>(g, st) : launch_gather<64, 128, 2, 2, TR, 32, 3>(g, st);
             }
-            return launch_gather<128, 128, 2, 2, TR, 32, true>(g, st);
+            return one ? launch_gather<128, 128, 2, 2, TR, 32, 1>(g, st) : launch_gather<128, 128, 2, 2, TR, 32, 3>(g, st);
         }
-        if (g.N > 32) return launch_gather<128, 64, 2, 2, TR, 32, true>(g, st);
-        return launch_gather<128, 32, 4, 1, TR, 32, true>(g, st);
+        if (g.N > 32) return one ? launch_gather<128, 64, 2, 2, TR, 32, 1>(g, st) : launch_gather<128, 64, 2, 2, TR, 32, 3>(g, st);
+        return one ? launch_gather<128, 32, 4, 1, TR, 32, 1>(g, st) : launch_gather<128, 32, 4, 1, TR, 32, 3>(g, st);
     }
     if (g.N > 64) {
         // LDS allows 2 resident blocks per CU at BK = 32 (74 KB) and 3 at BK = 16 (41 KB).  1x1 convs have
@@ -886,14 +909,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
 // are the plain ds_read_b128 of the gather kernel.  Each thread owns one 4-pixel x 4-channel block of
 // each operand per 32-pixel chunk (4 coalesced 16-B loads, a 4x4 register transpose folded into the
 // bf16 packing, 12 ds_write_b64).
-template <int TN_, int TJ_>
+template <int TN_, int TJ_, int NP = 3>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3(const WgradGeom g) {
     constexpr int MI = TN_ / 64, MJ = TJ_ / 64;
     constexpr int PITCH_B = 80;
     constexpr int NBLK_A = 8 * (TN_ / 4), NBLK_B = 8 * (TJ_ / 4);     // 4x4 blocks per chunk (<= 256)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* As = smem_b;                          // [3][TN_][80 B]
-    unsigned char* Bs = smem_b + 3 * TN_ * PITCH_B;      // [3][TJ_][80 B]
+    unsigned char* As = smem_b;                          // [NP][TN_][80 B]
+    unsigned char* Bs = smem_b + NP * TN_ * PITCH_B;     // [NP][TJ_][80 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
@@ -957,6 +980,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3(const WgradGeom g) {
     };
     // split 4 pixels x 4 channels and write the 4 channel rows (3 planes each) transposed
     auto split_store = [&](const f32x4 (&v)[4], unsigned char* base, int rows) {
+        if constexpr (NP == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u32x2 p;
+                p[0] = pack_hi16(rn_bf16_bits(v[1][e]), rn_bf16_bits(v[0][e]));
+                p[1] = pack_hi16(rn_bf16_bits(v[3][e]), rn_bf16_bits(v[2][e]));
+                *reinterpret_cast<u32x2*>(base + (cg * 4 + e) * PITCH_B + pg * 8) = p;
+            }
+            return;
+        }
         unsigned h1[4][4], h2[4][4], h3[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1004,27 +1037,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3(const WgradGeom g) {
             if (ch + 1 < nchunks) load_chunk();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[MI][3], fb[MJ][3];
+                bf16x8 fa[MI][NP], fb[MJ][NP];
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
                         fa[i][pl] = *reinterpret_cast<const bf16x8*>(a_frag + pl * TN_ * PITCH_B + i * 32 * PITCH_B + ks * 32);
 #pragma unroll
                 for (int jj = 0; jj < MJ; ++jj)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
+                    for (int pl = 0; pl < NP; ++pl)
                         fb[jj][pl] = *reinterpret_cast<const bf16x8*>(b_frag + pl * TJ_ * PITCH_B + jj * 32 * PITCH_B + ks * 32);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int jj = 0; jj < MJ; ++jj) {
                         f32x16 c = acc[i][jj];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[jj][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[jj][1], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][2], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[jj][0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][1], c, 0, 0, 0);
+                        if constexpr (NP == 3) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[jj][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[jj][1], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][2], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[jj][0], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][1], c, 0, 0, 0);
+                        }
                         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[jj][0], c, 0, 0, 0);
                         acc[i][jj] = c;
                     }
@@ -1098,11 +1133,12 @@ void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int stride, Wgrad
     g.splits = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
 }
 
-template <int TN_, int TJ_, bool SPLIT = false>
+template <int TN_, int TJ_, int NP = 0>
 int launch_wgrad(const WgradGeom& g, hipStream_t st) {
-    const size_t smem = SPLIT ? 3ull * (TN_ + TJ_) * 80 : 2ull * 32 * (TN_ + TJ_) * sizeof(float);
+    constexpr bool SPLIT = NP > 0;
+    const size_t smem = SPLIT ? (size_t)NP * (TN_ + TJ_) * 80 : 2ull * 32 * (TN_ + TJ_) * sizeof(float);
     void (*kern)(const WgradGeom);
-    if constexpr (SPLIT) kern = conv_wgrad_bf16x3<TN_, TJ_>;
+    if constexpr (SPLIT) kern = conv_wgrad_bf16x3<TN_, TJ_, (NP > 0 ? NP : 3)>;
     else kern = conv_wgrad_mfma_f32<TN_, TJ_>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1285,7 +1321,7 @@ constexpr int STEM_WAVES = 4096;
 extern "C" {
 
 int y4_set_conv_mode(int mode) {
-    if (mode != 0 && mode != 1) return Y4_ERR_SHAPE;
+    if (mode < 0 || mode > 2) return Y4_ERR_SHAPE;
     g_conv_mode = mode;
     return Y4_OK;
 }
@@ -1319,12 +1355,13 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
     const long long M = (long long)B * g.Hd * g.Wd;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cin; g.act = act;
-    if (g_conv_mode == 1) {
+    if (g_conv_mode != 0) {
         const long long nw = (long long)Cout * g.K;
         if (!g_scratch || g_scratch_bytes < (size_t)nw * 6) return Y4_ERR_WORKSPACE;   // y4_set_workspace() first
         unsigned short* planes = static_cast<unsigned short*>(g_scratch);
         const int blocks = (int)((nw + 255) / 256 > 4096 ? 4096 : (nw + 255) / 256);
-        hipLaunchKernelGGL(split_filter_kernel, dim3(blocks), dim3(256), 0, y4_stream(stream), w, planes, nw);
+        hipLaunchKernelGGL(split_filter_kernel, dim3(blocks), dim3(256), 0, y4_stream(stream), w, planes, nw,
+                           g_conv_mode == 2 ? 1 : 3);
         Y4_CHECK_LAUNCH();
         g.wt_planes = planes;
     }
@@ -1382,9 +1419,9 @@ int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, in
     float* wt = static_cast<float*>(workspace);
     const long long total = (long long)Cin * k * k * Cout_pad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    if (g_conv_mode == 1)
+    if (g_conv_mode != 0)
         hipLaunchKernelGGL(transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w,
-                           static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad);
+                           static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad, g_conv_mode == 2 ? 1 : 3);
     else
         hipLaunchKernelGGL(transpose_filter_kernel, dim3(blocks), dim3(256), 0, st, w, wt, Cout, Cin, k * k, Cout_pad);
     Y4_CHECK_LAUNCH();
@@ -1438,10 +1475,15 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
     }
     int rc;
     if (g_conv_mode == 1) {
-        if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, true>(g, st);
-        else if (g.tn == 128) rc = launch_wgrad<128, 64, true>(g, st);
-        else if (g.tj == 128) rc = launch_wgrad<64, 128, true>(g, st);
-        else rc = launch_wgrad<64, 64, true>(g, st);
+        if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, 3>(g, st);
+        else if (g.tn == 128) rc = launch_wgrad<128, 64, 3>(g, st);
+        else if (g.tj == 128) rc = launch_wgrad<64, 128, 3>(g, st);
+        else rc = launch_wgrad<64, 64, 3>(g, st);
+    } else if (g_conv_mode == 2) {
+        if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, 1>(g, st);
+        else if (g.tn == 128) rc = launch_wgrad<128, 64, 1>(g, st);
+        else if (g.tj == 128) rc = launch_wgrad<64, 128, 1>(g, st);
+        else rc = launch_wgrad<64, 64, 1>(g, st);
     } else if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128>(g, st);
     else if (g.tn == 128) rc = launch_wgrad<128, 64>(g, st);
     else if (g.tj == 128) rc = launch_wgrad<64, 128>(g, st);
