@@ -349,6 +349,49 @@ def test_head_and_loss_full_size_vs_oracle(dev):
         close(xs[l].grad, ref_grads[l], 1e-5, 1e-4)
 
 
+def test_loss_edge_cases_vs_oracle(dev):
+    """Ragged / empty label tensors: every image empty (objectness-only loss), K = 7 instead of 60, a truth on the
+    last cell, and a label whose class index is the last class."""
+    from yolov4_amd.yolo.model.yololayer import YOLOLayer
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    B, S = 3, 128
+    cases = {'all_empty': torch.zeros((B, 60, 5), dtype=torch.float64)}
+    lab = torch.zeros((B, 7, 5), dtype=torch.float64)
+    lab[0, 0] = torch.tensor([127.5, 127.5, 30.0, 40.0, 79.0])      # last cell of every grid, last class
+    lab[0, 1] = torch.tensor([0.5, 0.5, 100.0, 90.0, 0.0])          # first cell
+    lab[2, 0] = torch.tensor([64.0, 64.0, 120.0, 125.0, 17.0])      # cell boundary exactly
+    cases['k7'] = lab
+    for name, labels in cases.items():
+        crit = YOLOLoss(CFG, ignore_thresh=0.7, device=dev, mutate_outputs=False)
+        xs, outs, logits = [], [], []
+        for l, Fs in enumerate((16, 8, 4)):
+            lg = recipe.synth_head_logits(B, Fs, 800 + l)
+            logits.append(lg.numpy())
+            x = lg.to(dev).requires_grad_(True)
+            xs.append(x); outs.append(YOLOLayer(CFG, l, device=dev).train()(x))
+        loss = crit(outs, {'padded_labels': labels})
+        ref_loss, ref_grads = H.yolo_loss(logits, labels.numpy(), CFG, 0.7)
+        assert abs(float(loss.detach()) - ref_loss) <= 1e-4 * abs(ref_loss), name
+        loss.backward()
+        for l in range(3):
+            close(xs[l].grad, ref_grads[l], 1e-5, 1e-4)
+            _, obj_ref, tm_ref, _ = H.build_target(outs[l]['output'].detach().cpu().numpy(), outs[l]['pred'].detach().cpu().numpy(),
+                                                   l, labels.numpy(), CFG, 0.7)
+            _, obj, tm, _ = crit.build_target(outs[l]['output'], outs[l]['pred'], l, labels)
+            assert np.array_equal(obj.cpu().numpy(), obj_ref) and np.array_equal(tm.cpu().numpy(), tm_ref), (name, l)
+
+
+def test_postprocess_no_candidates_and_single_box(dev):
+    from yolov4_amd.yolo.util.utils import postprocess
+    p = torch.zeros((2, 50, 85), device=dev)
+    assert postprocess(p.clone(), 80, 0.5, 0.4) == [None, None]
+    p[1, 7, :5] = torch.tensor([100.0, 120.0, 40.0, 60.0, 0.9], device=dev)
+    p[1, 7, 5 + 33] = 0.8
+    out = postprocess(p, 80, 0.5, 0.4)
+    assert out[0] is None and out[1].shape == (1, 7)
+    np.testing.assert_allclose(out[1].cpu().numpy()[0], [80.0, 90.0, 120.0, 150.0, 0.9, 0.8, 33.0], rtol=1e-6)
+
+
 def test_postprocess_golden(dev, golden):
     from yolov4_amd.yolo.util.utils import postprocess
     g = golden('postprocess')
