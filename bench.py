@@ -81,7 +81,7 @@ class ConvTimer:
             Ho, Wo = ops.conv_out_hw(H, W, k, s)
             return 2.0 * B * Ho * Wo * w.shape[0] * Cin * k * k, (Cin, w.shape[0], k, s, H)
 
-        def f_dgrad(dy, w, x_shape, k, s):
+        def f_dgrad(dy, w, x_shape, k, s, addend=None):
             B, Cout, Ho, Wo = dy.shape
             return 2.0 * B * Ho * Wo * Cout * x_shape[1] * k * k, (x_shape[1], Cout, k, s, x_shape[2])
 

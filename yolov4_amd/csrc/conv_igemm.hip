@@ -1296,21 +1296,30 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradGeo
     }
 }
 
-// one block per output element: 256 threads fold the per-wave slabs (fp64, fixed order)
-__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                                int nslabs, int Cout) {
-    __shared__ double red[256];
-    const int i = blockIdx.x;                                 // over Cout*27
-    const int n = i / 27, j = i - n * 27;
-    double s = 0.0;
-    for (int k = threadIdx.x; k < nslabs; k += 256) s += (double)slabs[(long long)k * 1024 + n * 32 + j];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-        __syncthreads();
+// Two coalesced stages over the per-wave slabs [nslabs][32 n][32 j]: 64 blocks each fold nslabs/64 slabs for all
+// 1024 entries (thread <-> 4 consecutive entries, fp64), then one block folds the 64 partial rows in a fixed order.
+__global__ __launch_bounds__(256) void stem_wgrad_reduce1_kernel(const float* __restrict__ slabs, double* __restrict__ part,
+                                                                 int nslabs) {
+    const int per = (nslabs + gridDim.x - 1) / gridDim.x;
+    const int k0 = blockIdx.x * per;
+    const int k1 = min(nslabs, k0 + per);
+    double s[4] = {0, 0, 0, 0};
+    for (int k = k0; k < k1; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + (long long)k * 1024 + threadIdx.x * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += (double)v[e];
     }
-    if (threadIdx.x == 0) dw[i] = (float)red[0];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[(long long)blockIdx.x * 1024 + threadIdx.x * 4 + e] = s[e];
+}
+__global__ __launch_bounds__(256) void stem_wgrad_reduce2_kernel(const double* __restrict__ part, float* __restrict__ dw,
+                                                                 int nparts, int Cout) {
+    for (int i = threadIdx.x; i < Cout * 27; i += 256) {
+        const int n = i / 27, j = i - n * 27;
+        double s = 0.0;
+        for (int k = 0; k < nparts; ++k) s += part[(long long)k * 1024 + n * 32 + j];
+        dw[i] = (float)s;
+    }
 }
 
 constexpr int STEM_WAVES = 4096;
@@ -1404,10 +1413,12 @@ size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
     return (size_t)Cin * k * k * cp * 6;       // fp32 transposed filter (4 B) or 3 bf16 planes (6 B) per element
 }
 
-int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
-                        int B, int H, int W, int Cin, int Cout, int k, int stride,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                           int B, int H, int W, int Cin, int Cout, int k, int stride,
+                           const float* addend, int ld_addend,
+                           void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
+    if (addend && ld_addend < Cin) return Y4_ERR_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
     const int Cout_pad = (Cout + 31) / 32 * 32;
@@ -1427,9 +1438,9 @@ int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, in
     Y4_CHECK_LAUNCH();
     const int pad = (k - 1) / 2;
     ConvGeom g{};
-    g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = nullptr;
+    g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = addend;
     g.wt_planes = static_cast<const unsigned short*>(workspace);
-    g.lds_ = lddy; g.ldd = lddx; g.ldr = 0;
+    g.lds_ = lddy; g.ldd = lddx; g.ldr = ld_addend;
     g.B = B;
     g.Hs = (H + 2 * pad - k) / stride + 1;
     g.Ws = (W + 2 * pad - k) / stride + 1;
@@ -1439,6 +1450,13 @@ int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, in
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cout_pad; g.act = Y4_ACT_LINEAR;
     return dispatch_gather<true>(g, st);
+}
+
+int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                        int B, int H, int W, int Cin, int Cout, int k, int stride,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, nullptr, 0, workspace, workspace_bytes,
+                           stream);
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
@@ -1517,7 +1535,9 @@ int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long lo
     return Y4_OK;
 }
 
-size_t y4_conv2d_stem_wgrad_workspace(int, int, int, int) { return (size_t)STEM_WAVES * 1024 * sizeof(float); }
+size_t y4_conv2d_stem_wgrad_workspace(int, int, int, int) {
+    return (size_t)STEM_WAVES * 1024 * sizeof(float) + 64 * 1024 * sizeof(double);
+}
 
 int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
                              const float* dy, int lddy, float* dw, int B, int H, int W, int Cout,
@@ -1536,8 +1556,11 @@ int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long 
     hipStream_t st = y4_stream(stream);
     hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(STEM_WAVES / 4), dim3(256), 0, st, g);
     Y4_CHECK_LAUNCH();
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(Cout * 27), dim3(256), 0, st,
-                       static_cast<const float*>(workspace), dw, STEM_WAVES, Cout);
+    double* part = reinterpret_cast<double*>(static_cast<char*>(workspace) + (size_t)STEM_WAVES * 1024 * sizeof(float));
+    hipLaunchKernelGGL(stem_wgrad_reduce1_kernel, dim3(64), dim3(256), 0, st, static_cast<const float*>(workspace), part,
+                       STEM_WAVES);
+    Y4_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stem_wgrad_reduce2_kernel, dim3(1), dim3(256), 0, st, part, dw, 64, Cout);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
