@@ -251,6 +251,7 @@ def main():
                                            if args.conv_mode == 'bf16x3' else
                                            'plain bf16 MFMA operands (RN), fp32 accumulate; fp32 BN/loss/NMS (config 5, mixed precision)'
                                            if args.conv_mode == 'bf16' else 'fp32 MFMA fma chain (v_mfma_f32_32x32x2_f32)'),
+                       'peak_hbm_gib': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
                        'loss': lossv, 'conv_tflops_whole_step': value / world * flop_img / 1e12},
         }
         if timer.rec:

@@ -139,6 +139,27 @@ def test_conv_linearity_at_full_size(dev, conv_mode):
     close(y1[:1], ref)
 
 
+def test_conv_tensors_beyond_4gib(dev, conv_mode):
+    """Maximum sizes: a 6 GiB activation (B = 64, 64 ch @608x608).  Kernels address through 32-bit buffer windows
+    re-based per block, so the full-batch launch must equal the same kernels run on < 4 GiB sub-batches."""
+    from yolov4_amd import ops
+    B, Cin, Cout, Hh = 64, 64, 32, 608
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    x = torch.randn((B, Cin, Hh, Hh), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    assert x.numel() * 4 > (1 << 32)
+    w = (torch.randn((Cout, Cin, 1, 1), device=dev, generator=g) * 0.1).contiguous(memory_format=torch.channels_last)
+    y = ops.conv_fwd_raw(x, w, 1, 1)
+    for b0 in (0, 40):
+        assert torch.equal(y[b0:b0 + 24], ops.conv_fwd_raw(x[b0:b0 + 24], w, 1, 1))
+    # dgrad produces the > 4 GiB tensor, wgrad reduces over it
+    dy = torch.randn((B, Cout, Hh, Hh), device=dev, generator=g).contiguous(memory_format=torch.channels_last)
+    dx = ops.conv_dgrad_raw(dy, w, (B, Cin, Hh, Hh), 1, 1)
+    assert torch.equal(dx[40:64], ops.conv_dgrad_raw(dy[40:64], w, (24, Cin, Hh, Hh), 1, 1))
+    dw = ops.conv_wgrad_raw(x, dy, (Cout, Cin, 1, 1), 1, 1)
+    parts = sum(ops.conv_wgrad_raw(x[b0:b0 + 16], dy[b0:b0 + 16], (Cout, Cin, 1, 1), 1, 1).double() for b0 in range(0, 64, 16))
+    close(dw, parts, 1e-5, 1e-4)
+
+
 def test_conv_plain_bf16_mode(dev):
     """BASELINE config 5 arithmetic (bf16 MFMA operands, fp32 accumulate): mixed precision, so only a loose
     bound holds against the fp32 reference -- 2^-8 relative per operand -> ~1e-2 of the output range."""

@@ -38,7 +38,8 @@ struct ConvGeom {
     int cls_tile0[5];
     int cls_h[2], cls_w[2];       // class extents: (Hd + 1 - ph) / 2, (Wd + 1 - pw) / 2
     int cls_slot0[5];             // classed launch: per-XCD slot ranges (each XCD gets 1/8 of EVERY class)
-    unsigned src_bytes, wt_bytes; // extents for the buffer descriptors (< 4 GiB, checked on the host)
+    unsigned long long src_total_bytes;   // whole source tensor; each block re-bases its 32-bit buffer window at its first image
+    unsigned wt_bytes;            // filter extent for the buffer descriptor (< 4 GiB, checked on the host)
     const unsigned short* wt_planes;   // bf16x3 mode: filter pre-split into 3 bf16 planes [3][N][K] (library scratch)
 };
 
@@ -94,7 +95,14 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void conv_gather_mfma_f32
     const int lrow = tid / LPR, kc = tid % LPR;
 
     // ---- per-thread A-row bookkeeping (rows are fixed for the whole K loop); byte offsets, 32 bit
-    const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, g.src_bytes);
+    // 32-bit buffer offsets are relative to the first image this tile touches (tensors may exceed 4 GiB)
+    const int pix_per_img = classed ? g.cls_h[ph] * g.cls_w[pw] : g.Hd * g.Wd;
+    const int b_first = (int)(((long long)mt_local * BM) / pix_per_img);
+    const unsigned long long img_bytes = (unsigned long long)g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull;
+    const unsigned long long src_skip = (unsigned long long)b_first * img_bytes;
+    const unsigned long long src_left = g.src_total_bytes > src_skip ? g.src_total_bytes - src_skip : 0ull;
+    const __amdgpu_buffer_rsrc_t src_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.src) + src_skip, (unsigned)(src_left < 0xfffffff0ull ? src_left : 0xfffffff0ull));
     const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt, g.wt_bytes);
     const unsigned OOB = 0xffffffffu;                 // > any num_bytes: the load returns zeros
     unsigned a_base[PA];
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256, (BKT == 16 ? 3 : 2)) void conv_gather_mfma_f32
             hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
         }
         if (kc == 0) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
-        a_base[p] = (unsigned)b * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
+        a_base[p] = (unsigned)(b - b_first) * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
         if (!TRANSPOSED) {
             a_h[p] = hd * g.stride - g.pad;
             a_w[p] = wd * g.stride - g.pad;
@@ -378,7 +386,14 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     const int nr = (g.k - r0 + tstep - 1) / tstep, nq = (g.k - q0 + tstep - 1) / tstep;
     const int lrow = tid >> 3, kc = tid & 7;
 
-    const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, g.src_bytes);
+    // 32-bit buffer offsets are relative to the first image this tile touches (tensors may exceed 4 GiB)
+    const int pix_per_img = classed ? g.cls_h[ph] * g.cls_w[pw] : g.Hd * g.Wd;
+    const int b_first = (int)(((long long)mt_local * BM) / pix_per_img);
+    const unsigned long long img_bytes = (unsigned long long)g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull;
+    const unsigned long long src_skip = (unsigned long long)b_first * img_bytes;
+    const unsigned long long src_left = g.src_total_bytes > src_skip ? g.src_total_bytes - src_skip : 0ull;
+    const __amdgpu_buffer_rsrc_t src_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.src) + src_skip, (unsigned)(src_left < 0xfffffff0ull ? src_left : 0xfffffff0ull));
     const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt_planes, g.wt_bytes);     // 3 planes of N*K bf16
     const unsigned OOB = 0xffffffffu;
     unsigned a_base[PA];
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
             hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
         }
         if (kc == 0) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
-        a_base[p] = (unsigned)b * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
+        a_base[p] = (unsigned)(b - b_first) * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
         if (!TRANSPOSED) { a_h[p] = hd * g.stride - g.pad; a_w[p] = wd * g.stride - g.pad; }
         else { a_h[p] = hd + g.pad; a_w[p] = wd + g.pad; }
     }
@@ -672,10 +687,12 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
     }
     g.ntiles = (g.N + BN - 1) / BN;
     {
-        const unsigned long long sb = (unsigned long long)g.B * g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull;
+        const unsigned long long img = (unsigned long long)g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull;
         const unsigned long long wb = (unsigned long long)g.N * g.K * 4ull;
-        if (sb >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;   // 32-bit buffer offsets
-        g.src_bytes = (unsigned)sb; g.wt_bytes = (unsigned)wb;
+        // a tile's window spans the images of BM consecutive output pixels (+1): must fit 32-bit offsets
+        const unsigned long long imgs_per_tile = (unsigned long long)BM / (unsigned long long)((g.Hd * g.Wd + 3) / 4 > 0 ? (g.Hd * g.Wd + 3) / 4 : 1) + 2;
+        if (img * imgs_per_tile >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+        g.src_total_bytes = (unsigned long long)g.B * img; g.wt_bytes = (unsigned)wb;
         if (SPLIT) {
             if (!g.wt_planes) return Y4_ERR_WORKSPACE;
             g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * NP);
@@ -764,7 +781,7 @@ struct WgradGeom {
     int J;          // k*k*Cin
     int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
     int tn, tj;     // tile edges chosen by the planner (64 or 128)
-    unsigned x_bytes, dy_bytes;
+    unsigned long long x_total_bytes, dy_total_bytes;   // whole tensors; blocks re-base their 32-bit windows
 };
 
 // D[n][j] = sum_p dy[p][n] * xg[p][j].  Block tile TN_ x TJ_ (64 or 128 each), 4 waves as 2x2,
@@ -802,23 +819,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_f32(const WgradGeom g)
     if (nchunks > g.chunks_per_split) nchunks = g.chunks_per_split;
 
     // running (b, ho, wo) of this thread's B rows: advanced by 32 pixels per chunk, no divisions
-    const __amdgpu_buffer_rsrc_t x_rsrc = y4_make_rsrc(g.x, g.x_bytes);
-    const __amdgpu_buffer_rsrc_t dy_rsrc = y4_make_rsrc(g.dy, g.dy_bytes);
+    // 32-bit buffer windows start at this block's first pixel (dy) / first image (x)
+    const long long p_first = (long long)chunk0 * 32;
+    const int b_first = (int)(p_first / ((long long)g.Ho * g.Wo));
+    const unsigned long long x_skip = (unsigned long long)b_first * g.H * g.W * (unsigned long long)g.ldx * 4ull;
+    const unsigned long long dy_skip = (unsigned long long)p_first * (unsigned long long)g.lddy * 4ull;
+    const unsigned long long x_left = g.x_total_bytes > x_skip ? g.x_total_bytes - x_skip : 0ull;
+    const unsigned long long dy_left = g.dy_total_bytes > dy_skip ? g.dy_total_bytes - dy_skip : 0ull;
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.x) + x_skip, (unsigned)(x_left < 0xfffffff0ull ? x_left : 0xfffffff0ull));
+    const __amdgpu_buffer_rsrc_t dy_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.dy) + dy_skip, (unsigned)(dy_left < 0xfffffff0ull ? dy_left : 0xfffffff0ull));
     const unsigned OOB = 0xffffffffu;
     int pb_b[PB], pb_h[PB], pb_w[PB];
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
         const int pix = chunk0 * 32 + p * RPP_B + brow;
-        const int pp = pix < g.M ? pix : 0;
-        pb_b[p] = pp / (g.Ho * g.Wo);
-        const int rem = pp - pb_b[p] * (g.Ho * g.Wo);
+        const int pp = pix < g.M ? pix : (int)p_first;
+        const int bb = pp / (g.Ho * g.Wo);
+        pb_b[p] = bb - b_first;                            // image index relative to the block's window
+        const int rem = pp - bb * (g.Ho * g.Wo);
         pb_h[p] = rem / g.Wo;
         pb_w[p] = rem - pb_h[p] * g.Wo;
     }
     unsigned a_off[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p)
-        a_off[p] = an_ok ? (unsigned)(chunk0 * 32 + p * RPP_A + arow) * (unsigned)g.lddy * 4u + (unsigned)(n0 + ac4) * 4u : OOB;
+        a_off[p] = an_ok ? (unsigned)(p * RPP_A + arow) * (unsigned)g.lddy * 4u + (unsigned)(n0 + ac4) * 4u : OOB;
     const unsigned chunk_bytes = 32u * (unsigned)g.lddy * 4u;
     const unsigned x_pix_bytes = (unsigned)g.ldx * 4u;
 
@@ -940,20 +967,30 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3(const WgradGeom g) {
     int nchunks = (g.M + 31) / 32 - chunk0;
     if (nchunks > g.chunks_per_split) nchunks = g.chunks_per_split;
 
-    const __amdgpu_buffer_rsrc_t x_rsrc = y4_make_rsrc(g.x, g.x_bytes);
-    const __amdgpu_buffer_rsrc_t dy_rsrc = y4_make_rsrc(g.dy, g.dy_bytes);
+    // 32-bit buffer windows start at this block's first pixel (dy) / first image (x)
+    const long long p_first = (long long)chunk0 * 32;
+    const int b_first = (int)(p_first / ((long long)g.Ho * g.Wo));
+    const unsigned long long x_skip = (unsigned long long)b_first * g.H * g.W * (unsigned long long)g.ldx * 4ull;
+    const unsigned long long dy_skip = (unsigned long long)p_first * (unsigned long long)g.lddy * 4ull;
+    const unsigned long long x_left = g.x_total_bytes > x_skip ? g.x_total_bytes - x_skip : 0ull;
+    const unsigned long long dy_left = g.dy_total_bytes > dy_skip ? g.dy_total_bytes - dy_skip : 0ull;
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.x) + x_skip, (unsigned)(x_left < 0xfffffff0ull ? x_left : 0xfffffff0ull));
+    const __amdgpu_buffer_rsrc_t dy_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.dy) + dy_skip, (unsigned)(dy_left < 0xfffffff0ull ? dy_left : 0xfffffff0ull));
     const unsigned OOB = 0xffffffffu;
     int pb_b[4], pb_h[4], pb_w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int pix = chunk0 * 32 + pg * 4 + i;
-        const int pp = pix < g.M ? pix : 0;
-        pb_b[i] = pp / (g.Ho * g.Wo);
-        const int rem = pp - pb_b[i] * (g.Ho * g.Wo);
+        const int pp = pix < g.M ? pix : (int)p_first;
+        const int bb = pp / (g.Ho * g.Wo);
+        pb_b[i] = bb - b_first;
+        const int rem = pp - bb * (g.Ho * g.Wo);
         pb_h[i] = rem / g.Wo;
         pb_w[i] = rem - pb_h[i] * g.Wo;
     }
-    const unsigned a_off0 = an_ok ? (unsigned)(chunk0 * 32 + pg * 4) * (unsigned)g.lddy * 4u + (unsigned)(n0 + cg * 4) * 4u : OOB;
+    const unsigned a_off0 = an_ok ? (unsigned)(pg * 4) * (unsigned)g.lddy * 4u + (unsigned)(n0 + cg * 4) * 4u : OOB;
     const unsigned dy_pix_bytes = (unsigned)g.lddy * 4u;
     const unsigned chunk_bytes = 32u * dy_pix_bytes;
     const unsigned x_pix_bytes = (unsigned)g.ldx * 4u;
@@ -1130,6 +1167,13 @@ void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int stride, Wgrad
     }
     { static const char* fs = getenv("Y4_WGRAD_SPLITS"); if (fs) { best_s = atoi(fs); if (best_s > max_s) best_s = max_s; if (best_s < 1) best_s = 1; } }
     g.chunks_per_split = (chunks + best_s - 1) / best_s;
+    // a block's pixel range (+ 2 images of slack) must fit a 32-bit buffer window; planned for pitches up to 2x the
+    // channel count (channel slices of concat buffers), verified against the real pitches at call time
+    const unsigned long long per_px = 8ull * (unsigned long long)((Cout + 3) / 4 * 4 > Cin * stride * stride ? (Cout + 3) / 4 * 4 : Cin * stride * stride);
+    const unsigned long long slack = 2ull * g.Ho * g.Wo;
+    const unsigned long long max_px = 0xf0000000ull / per_px;
+    if (max_px > slack + 32 && (unsigned long long)g.chunks_per_split * 32ull + slack > max_px)
+        g.chunks_per_split = (int)((max_px - slack) / 32ull);
     g.splits = (chunks + g.chunks_per_split - 1) / g.chunks_per_split;
 }
 
@@ -1478,10 +1522,11 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
     if ((long long)B * g.Ho * g.Wo >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.x = x; g.dy = dy; g.ldx = ldx; g.lddy = lddy;
     {
-        const unsigned long long xb = (unsigned long long)B * H * W * (unsigned long long)ldx * 4ull;
-        const unsigned long long db = (unsigned long long)B * g.Ho * g.Wo * (unsigned long long)lddy * 4ull;
-        if (xb >= 0xfffffff0ull || db >= 0xfffffff0ull) return Y4_ERR_SHAPE;   // 32-bit buffer offsets
-        g.x_bytes = (unsigned)xb; g.dy_bytes = (unsigned)db;
+        g.x_total_bytes = (unsigned long long)B * H * W * (unsigned long long)ldx * 4ull;
+        g.dy_total_bytes = (unsigned long long)B * g.Ho * g.Wo * (unsigned long long)lddy * 4ull;
+        const unsigned long long range_px = (unsigned long long)g.chunks_per_split * 32ull + 2ull * g.Ho * g.Wo;
+        const unsigned long long per_px = 4ull * (unsigned long long)(lddy > ldx * stride * stride ? lddy : ldx * stride * stride);
+        if (range_px * per_px >= 0xfffffff0ull) return Y4_ERR_SHAPE;      // pitch more than 2x the channel count at > 4 GiB
     }
     hipStream_t st = y4_stream(stream);
     if (g.splits > 1) {
