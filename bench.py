@@ -239,7 +239,7 @@ def main():
         value = world * B * args.steps / dt
         flop_img = FLOP_PER_IMG_608 * (S / 608.0) ** 2
         out = {
-            'metric': 'images/sec fwd+bwd @608x608 bs=64 per GPU (YOLOv4 training step: forward + YOLOLoss + backward)',
+            'metric': f'images/sec fwd+bwd @{S}x{S} bs={B} per GPU (YOLOv4 training step: forward + YOLOLoss + backward)',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if args.conv_mode == 'bf16' else 'f32', 'data': 'synthetic',
