@@ -14,6 +14,7 @@ SHAPES = [  # Cin, Cout, k, s, H
     (128, 128, 3, 1, 76), (256, 256, 3, 1, 38), (512, 512, 3, 1, 19), (256, 512, 3, 1, 38), (512, 1024, 3, 1, 19),
     (128, 256, 3, 1, 76), (64, 64, 1, 1, 304), (512, 256, 1, 1, 38), (64, 128, 3, 2, 304), (32, 64, 3, 2, 608),
     (256, 512, 3, 2, 76), (64, 64, 3, 1, 152), (128, 128, 1, 1, 76),
+    (64, 64, 1, 1, 152), (32, 64, 3, 1, 304), (64, 32, 1, 1, 304),
     (256, 128, 1, 1, 76), (1024, 512, 1, 1, 19), (256, 256, 1, 1, 38), (128, 64, 1, 1, 304), (512, 512, 1, 1, 19),
 ]
 if only:
