@@ -255,6 +255,14 @@ int y4_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------- eval input pipeline ("next" row 4)
+ * One image: src is uint8 HWC (3 channels, row pitch in bytes), as cv2.imread hands it to the reference.
+ * Resizes to SxS with the arithmetic of cv2.resize INTER_LINEAR on 8-bit data (yolo/data/transform.py:173-174),
+ * swaps B and R when swap_rb (transform.py:437), divides by 255 in fp32 and writes channel-planar
+ * (transform.py:461): dst[c*dst_sc + y*dst_sh + x*dst_sw], strides in elements (NCHW or NHWC slot of a batch). */
+int y4_preprocess_u8_f32(const void* src, int src_h, int src_w, long long src_pitch_bytes, int swap_rb,
+                         float* dst, long long dst_sc, long long dst_sh, long long dst_sw, int S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

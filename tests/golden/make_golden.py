@@ -380,7 +380,37 @@ def gen_model():
     save('model.npz', **arrs)
 
 
-GENS = {'iou_nms': gen_iou_nms, 'yololayer': gen_yololayer, 'yololoss': gen_yololoss,
+def gen_coco():
+    """validate()'s detection -> COCO-record arithmetic (yolo/engine/build.py:144-164): the reference's own
+    yolobox2xywh on Python floats taken from fp32 detections.  (engine/build.py itself needs apex/pycocotools
+    and cannot be imported; the per-detection calls are made here exactly as that loop makes them.)"""
+    from yolo.util.utils import yolobox2xywh
+    rng = np.random.RandomState(77)
+    arrs = {}
+    for ci, (sh, sw, S, n) in enumerate([(480, 640, 416, 23), (333, 500, 608, 40), (1216, 1216, 608, 5)]):
+        x1 = rng.uniform(0, S * 0.8, n); y1 = rng.uniform(0, S * 0.8, n)
+        det = np.stack([x1, y1, x1 + rng.uniform(2, S * 0.2, n), y1 + rng.uniform(2, S * 0.2, n),
+                        rng.uniform(0.01, 1, n), rng.uniform(0.01, 1, n), rng.randint(0, 80, n)], 1).astype(np.float32)
+        out = torch.from_numpy(det)
+        info = [sh, sw, S, S]
+        bbox, score = [], []
+        for o in out:
+            bbox.append(yolobox2xywh((float(o[1]), float(o[0]), float(o[3]), float(o[2])), info[:4]))
+            score.append(float(o[4].data.item() * o[5].data.item()))
+        arrs[f'c{ci}.det'] = det
+        arrs[f'c{ci}.info'] = np.asarray(info)
+        arrs[f'c{ci}.bbox'] = np.asarray(bbox, dtype=np.float64)
+        arrs[f'c{ci}.score'] = np.asarray(score, dtype=np.float64)
+    # the class-index -> COCO category-id table is data held by yolo/data/cocodataset.py (not importable: cv2);
+    # read the literal out of the file's text
+    import ast
+    import re
+    txt = open('/root/reference/yolo/data/cocodataset.py').read()
+    arrs['class_ids'] = np.asarray(ast.literal_eval(re.search(r'coco_class_ids = (\[[^\]]*\])', txt).group(1)))
+    save('coco.npz', **arrs)
+
+
+GENS = {'coco': gen_coco, 'iou_nms': gen_iou_nms, 'yololayer': gen_yololayer, 'yololoss': gen_yololoss,
         'postprocess': gen_postprocess, 'convbnact': gen_convbnact, 'blocks': gen_blocks, 'model': gen_model}
 
 if __name__ == '__main__':

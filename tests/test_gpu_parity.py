@@ -553,6 +553,33 @@ def test_model_train_step_golden(dev, golden, hip_model):
             close(m.state_dict()[k[15:]], g[k], 1e-5, 1e-4)
 
 
+def test_wgrad_on_side_stream_is_identical(dev, golden, hip_model):
+    """Opt-in mode: filter gradients produced on a second HIP stream and accumulated into .grad outside
+    autograd.  Kernels are deterministic, so both schedules must give the same bits -- twice (accumulate)."""
+    from yolov4_amd import ops
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    m = hip_model
+    _reset(m, golden)
+    m.train()
+    x = recipe.randn((2, 3, 128, 128), 80).to(dev)
+    labels = recipe.synth_labels(2, 128, 81, counts=[9, 21])
+    crit = YOLOLoss(CFG, ignore_thresh=0.7, device=dev, mutate_outputs=False)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    grads = {}
+    for on in (False, True):
+        m.load_state_dict(sd)
+        m.zero_grad(set_to_none=True)
+        ops.set_async_wgrad(on)
+        try:
+            for _ in range(2):
+                crit(m(x), {'padded_labels': labels}).backward()
+        finally:
+            ops.set_async_wgrad(False)
+        grads[on] = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for k in grads[False]:
+        assert torch.equal(grads[False][k], grads[True][k]), k
+
+
 def test_gradients_within_reference_rounding(dev, golden, hip_model):
     """Same linear functional of the head logits on three backends: CPU fp64 (truth), CPU fp32 (the
     reference's arithmetic: torch ATen), HIP fp32.  The HIP path must be as close to the truth as the

@@ -91,3 +91,52 @@ def test_fused_adam_matches_torch_adam():
         ref.step(); hip.step()
     for rp, hp in zip(ref_p, hip_p):
         np.testing.assert_allclose(hp.detach().cpu().numpy(), rp.detach().numpy(), rtol=2e-6, atol=2e-7)
+
+
+# ------------------------------------------------------------------ row 4: eval input pipeline + COCO records
+def test_coco_class_table_and_records_golden():
+    from yolov4_amd.yolo.util.utils import COCO_CLASS_IDS, detections_to_coco
+    assert len(COCO_CLASS_IDS) == 80 and COCO_CLASS_IDS[0] == 1 and COCO_CLASS_IDS[-1] == 90
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'coco.npz'))
+    assert COCO_CLASS_IDS == list(g['class_ids'])                              # the reference's table, as data
+    for ci in range(3):
+        det = torch.from_numpy(g[f'c{ci}.det'])
+        recs = detections_to_coco(det, list(g[f'c{ci}.info']), image_id=42 + ci)
+        assert len(recs) == det.shape[0]
+        for r, bb, sc, d in zip(recs, g[f'c{ci}.bbox'], g[f'c{ci}.score'], g[f'c{ci}.det']):
+            assert r['bbox'] == list(bb) and r['score'] == sc                    # double arithmetic: bit-exact
+            assert r['category_id'] == COCO_CLASS_IDS[int(d[6])] and r['image_id'] == 42 + ci
+    assert detections_to_coco(None, [1, 1, 1, 1], 0) == []
+
+
+def _float_bilinear(img, S):
+    x = torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None]
+    return torch.nn.functional.interpolate(x, size=(S, S), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
+
+
+@pytest.mark.parametrize('shape,S', [((48, 64), 32), ((37, 53), 64), ((64, 64), 64), ((128, 128), 64), ((5, 7), 16)])
+def test_resize_oracle_within_one_lsb_of_float_bilinear(shape, S):
+    """cv2 is absent (parity unpinned): the fixed-point restatement must agree with exact bilinear sampling at
+    the same half-pixel-centre coordinates to 1 LSB (the box average of the 2x case equals bilinear there)."""
+    from oracle import preprocess as OP
+    img = np.random.RandomState(shape[0] * 131 + S).randint(0, 256, shape + (3,)).astype(np.uint8)
+    got = OP.resize_linear_u8(img, S).astype(np.float64)
+    assert np.abs(got - _float_bilinear(img, S)).max() <= 1.0
+    if shape == (S, S):
+        assert np.array_equal(got, img)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,S', [((480, 640), 416), ((333, 500), 608), ((1216, 1216), 608), ((608, 608), 608),
+                                     ((9, 1300), 64), ((31, 17), 416)])
+def test_gpu_val_transform_bit_exact_vs_oracle(shape, S):
+    from oracle import preprocess as OP
+    from yolov4_amd.yolo.data.transform import val_batch, val_transform
+    img = np.random.RandomState(shape[1] + S).randint(0, 256, shape + (3,)).astype(np.uint8)
+    ref, info_ref = OP.val_input(img, S)
+    out, info = val_transform(img, S)
+    assert info == info_ref
+    assert np.array_equal(out.cpu().numpy(), ref)
+    batch, infos = val_batch([img, img[:, ::-1]], S)                         # strided view as second image
+    assert np.array_equal(batch[0].cpu().numpy(), ref)
+    assert np.array_equal(batch[1].cpu().numpy(), OP.val_input(np.ascontiguousarray(img[:, ::-1]), S)[0])

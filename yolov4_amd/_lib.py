@@ -67,6 +67,7 @@ PROTOTYPES = {
     'y4_nms_workspace': (Z, [L]),
     'y4_nms_f32': (I, [P, P, L, F, I, P, P, P, Z, P]),
     'y4_adam_step_f32': (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
+    'y4_preprocess_u8_f32': (I, [P, I, I, L, I, P, L, L, L, I, P]),
 }
 
 _lib = None

@@ -69,6 +69,7 @@ class ConvBNAct(nn.Module):
             # e.g. after load_state_dict into a freshly built module on another device
             self.conv.weight.data = w.data.contiguous(memory_format=torch.channels_last)
             w = self.conv.weight
+        cfg['weight_param'] = self.conv.weight       # its gradient may be produced on the side stream (ops._wgrad_to_param)
         return ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
 
 

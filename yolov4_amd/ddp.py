@@ -52,7 +52,10 @@ class BucketedDDP(torch.nn.Module):
         self._hooks = []
         for b in self.buckets:
             for p in b.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(b)))
+                hook = self._make_hook(b)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+                # gradients produced outside autograd (yolov4_amd.ops: wgrad on the side stream) report here
+                p._y4_grad_ready = (lambda h=hook, q=p: h(q))
         self.zero_grad()
 
     # -- setup
@@ -97,8 +100,25 @@ class BucketedDDP(torch.nn.Module):
             b.launched = True
             return
         op = dist.ReduceOp.AVG if self.backend == 'nccl' else dist.ReduceOp.SUM
+        if b.flat.is_cuda:
+            # gradients of one bucket are written from two streams (main: BN/bias grads, side: filter grads):
+            # the collective is ordered after both
+            cur = torch.cuda.current_stream(b.flat.device)
+            for st in self._producer_streams(b.flat.device):
+                if st != cur:
+                    cur.wait_stream(st)
         b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
         b.launched = True
+
+    @staticmethod
+    def _producer_streams(device):
+        sts = [torch.cuda.default_stream(device)]
+        try:
+            from . import ops
+            sts.extend(st for st in ops._ASYNC['streams'].values() if st.device == device)
+        except Exception:
+            pass
+        return sts
 
     # -- per step
     def zero_grad(self, set_to_none=False):
@@ -118,6 +138,9 @@ class BucketedDDP(torch.nn.Module):
     def finish_backward(self):
         """Call after loss.backward(): waits for the bucket exchanges (stream-wise: the current stream
         waits for RCCL's) and applies the 1/world average where the backend has no AVG."""
+        if self.buckets and self.buckets[0].flat.is_cuda:
+            from . import ops
+            ops.join_side_stream()
         if self.accumulating:                 # local accumulation only: exchange happens on the last micro-step
             return
         for b in self.buckets:

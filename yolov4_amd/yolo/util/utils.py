@@ -91,3 +91,35 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45):
         det = rows.index_select(0, sel)
         out[b] = det.cpu() if on_host else det
     return out
+
+
+# ------------------------------------------------------------------ detections -> COCO records
+# the 80 COCO category ids in class-index order (yolo/data/cocodataset.py:48-51): 1..90 minus the unused ids
+COCO_CLASS_IDS = [i for i in range(1, 91) if i not in (12, 26, 29, 30, 45, 66, 68, 69, 71, 83)]
+
+
+def yolobox2xywh(box, info_img):
+    """(y1, x1, y2, x2) in network-input pixels -> [x1, y1, w, h] in source-image pixels
+    (yolo/util/utils.py:281-309); `info_img` = (src_h, src_w, dst_h, dst_w)."""
+    src_h, src_w, dst_h, dst_w = info_img
+    y1, x1, y2, x2 = box
+    box_h = (y2 - y1) / dst_h * src_h
+    box_w = (x2 - x1) / dst_w * src_w
+    return [x1 / dst_w * src_w, y1 / dst_h * src_h, box_w, box_h]
+
+
+def detections_to_coco(detections, img_info, image_id, class_ids=COCO_CLASS_IDS):
+    """One image's postprocess() result [n,7] (or None) -> list of COCO result dicts, as validate() builds
+    them (yolo/engine/build.py:144-164).  The reference converts every fp32 number to a Python float and
+    does the arithmetic in double precision; one device->host copy and the same double arithmetic here."""
+    if detections is None:
+        return []
+    d = detections.detach().cpu().numpy().astype(np.float64)
+    out = []
+    for r in d:
+        out.append({'image_id': image_id,
+                    'category_id': class_ids[int(r[6])],
+                    'bbox': yolobox2xywh((float(r[1]), float(r[0]), float(r[3]), float(r[2])), img_info[:4]),
+                    'score': float(r[4] * r[5]),
+                    'segmentation': []})
+    return out
