@@ -130,9 +130,11 @@ int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long 
  *   bytes (fp64 accumulators + per-block fp32 partial rows; no contended atomics).
  * y4_bn_finalize_partials_f32: same outputs from the per-M-tile column sums [nparts][2][C] that
  *   y4_conv2d_fwd_bnstats_f32 / y4_conv2d_stem_fwd_f32 leave behind (statistics fused into the conv
- *   epilogue: the conv output is not read again).  workspace: 2*C doubles.
+ *   epilogue: the conv output is not read again).  workspace: y4_bn_finalize_workspace(C) bytes.
+ * All reductions are two-stage and fixed-order (fp32 partial rows -> <= 64 fp64 rows -> one), i.e. deterministic.
  */
 size_t y4_bn_workspace(long long M, int C);
+size_t y4_bn_finalize_workspace(int C);
 int y4_bn_stats_f32(const float* y, int ldy, long long M, int C, float* mean, float* invstd,
                     float* running_mean, float* running_var, long long* num_batches_tracked,
                     float momentum, float eps, void* workspace, size_t workspace_bytes, void* stream);

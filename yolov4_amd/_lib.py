@@ -41,6 +41,7 @@ PROTOTYPES = {
     'y4_conv2d_stem_wgrad_workspace': (Z, [I, I, I, I]),
     'y4_conv2d_stem_wgrad_f32': (I, [P, L, L, L, L, P, I, P, I, I, I, I, P, Z, P]),
     'y4_bn_workspace': (Z, [L, I]),
+    'y4_bn_finalize_workspace': (Z, [I]),
     'y4_bn_finalize_partials_f32': (I, [P, L, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_stats_f32': (I, [P, I, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P]),

@@ -727,9 +727,194 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
 int g_conv_mode = 1;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs; default),
                               // 2: plain bf16 operands (RN), fp32 accumulate -- mixed precision, BASELINE config 5
 
+// ---------------------------------------------------------------- streaming 1x1 kernel (small K, small N)
+// The 1x1 layers on the 304^2 / 152^2 maps are HBM-bound (K, N <= 128: < 64 flop per byte); the tile machinery
+// above spends their time in prologues, barriers and LDS round trips.  Here the whole filter (3 bf16 planes)
+// stays in LDS for the life of a persistent block, and every wave streams its own 32 pixel rows from global
+// memory straight into the MFMA A-operand layout (lane = pixel, 8 consecutive channels = 32 contiguous bytes),
+// splits them in registers and never meets a barrier; the next tile's loads fly under this tile's MFMAs/stores.
+// Used for forward (filter planes [N][K]) and for 1x1 dgrad (planes of the transposed filter).
+template <int KS, int NT>
+__global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g) {
+    constexpr int K = KS * 16;
+    constexpr int PITCH = K * 2 + 16;                    // LDS row pitch: conflict-free ds_read_b128 for K = 32/64/128
+    constexpr int N32 = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    {
+        constexpr int CPR = K / 8;                       // 16-B chunks per filter row
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(g.wt_planes);
+        for (int i = tid; i < 3 * N32 * CPR; i += 256) {
+            const int pl = i / (N32 * CPR);
+            const int rem = i - pl * (N32 * CPR);
+            const int row = rem / CPR, ch = rem - row * CPR;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < g.N) v = *reinterpret_cast<const u32x4*>(wp + ((size_t)pl * g.N + row) * (K * 2) + ch * 16);
+            *reinterpret_cast<u32x4*>(smem_b + (pl * N32 + row) * PITCH + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, (unsigned)g.src_total_bytes);   // < 4 GiB (host)
+    const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
+    const int mtiles = g.mtiles;
+    f32x4 ra0[KS][2], ra1[KS][2];
+    auto load = [&](f32x4 (&ra)[KS][2], int tile) {
+        const int m = tile * 128 + wave * 32 + fr;
+        const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 32u : 0xffffffffu;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            ra[ks][0] = y4_buf_load4(src_rsrc, off, (unsigned)ks * 64u);
+            ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)ks * 64u + 16u);
+        }
+    };
+    float cs[NT], css[NT];
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        cs[j] = 0.f; css[j] = 0.f;
+        const int n = j * 32 + fr;
+        sc[j] = (g.scale && n < g.N) ? g.scale[n] : 1.0f;
+        sh[j] = (g.shift && n < g.N) ? g.shift[n] : 0.0f;
+    }
+    const unsigned char* b_frag = smem_b + fr * PITCH + fh * 16;
+    auto compute = [&](f32x4 (&ra)[KS][2], int tile) {
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            u32x2 a1, a2, a3, b1, b2, b3;
+            split3x4(ra[ks][0], a1, a2, a3);
+            split3x4(ra[ks][1], b1, b2, b3);
+            const u32x4 q1 = {a1[0], a1[1], b1[0], b1[1]}, q2 = {a2[0], a2[1], b2[0], b2[1]}, q3 = {a3[0], a3[1], b3[0], b3[1]};
+            bf16x8 fa[3];
+            fa[0] = __builtin_bit_cast(bf16x8, q1); fa[1] = __builtin_bit_cast(bf16x8, q2); fa[2] = __builtin_bit_cast(bf16x8, q3);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bf16x8 fb[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    fb[pl] = *reinterpret_cast<const bf16x8*>(b_frag + (pl * N32 + j * 32) * PITCH + ks * 32);
+                f32x16 c = acc[j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[0], c, 0, 0, 0);
+                acc[j] = c;
+            }
+        }
+        const int mbase = tile * 128 + wave * 32 + 4 * fh;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 32 + fr;
+            const bool nok = n < g.N;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float raw = acc[j][e];
+                cs[j] += raw; css[j] += raw * raw;           // rows past M are exact zeros
+                const int m = mbase + (e & 3) + 8 * (e >> 2);
+                if (nok && m < g.M) {
+                    float v = raw * sc[j] + sh[j];
+                    v = y4_act(v, g.act);
+                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    g.dst[(long long)m * g.ldd + n] = v;
+                }
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < mtiles) load(ra0, tile);
+    while (tile < mtiles) {
+        const int t1 = tile + gridDim.x;
+        if (t1 < mtiles) load(ra1, t1);
+        compute(ra0, tile);
+        if (t1 >= mtiles) break;
+        const int t2 = t1 + gridDim.x;
+        if (t2 < mtiles) load(ra0, t2);
+        compute(ra1, t1);
+        tile = t2;
+    }
+    if (g.stats) {                                        // one partial row per block: [gridDim][2][N]
+        __syncthreads();                                  // every wave is done with the filter planes
+        float* red = reinterpret_cast<float*>(smem_b);    // [4][N32][2]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = cs[j], b = css[j];
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (fh == 0) { red[(wave * N32 + j * 32 + fr) * 2] = a; red[(wave * N32 + j * 32 + fr) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        for (int c = tid; c < N32; c += 256) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[(w * N32 + c) * 2]; b += red[(w * N32 + c) * 2 + 1]; }
+            if (c < g.N) {
+                g.stats[((long long)blockIdx.x * 2 + 0) * g.N + c] = a;
+                g.stats[((long long)blockIdx.x * 2 + 1) * g.N + c] = b;
+            }
+        }
+    }
+}
+
+template <int KS, int NT>
+int launch_stream1x1(const ConvGeom& g0, hipStream_t st, int* nparts) {
+    ConvGeom g = g0;
+    g.mtiles = (g.M + 127) / 128;
+    g.ntiles = 1;
+    g.src_total_bytes = (unsigned long long)g.M * (unsigned long long)g.lds_ * 4ull;
+    const size_t smem = (size_t)3 * NT * 32 * (KS * 32 + 16);
+    auto kern = conv1x1_stream_bf16x3<KS, NT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int grid = g.mtiles < 512 ? g.mtiles : 512;     // 2 resident blocks per CU
+    if (nparts) *nparts = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+// eligibility: bf16x3 arithmetic, 1x1 stride 1, K in {32,64}, N <= 128, filter planes <= 52 KB of LDS,
+// 32-bit addressable source, every source channel valid, and enough rows to be worth a persistent launch
+static bool stream1x1_ok(const ConvGeom& g) {
+    if (g_conv_mode != 1 || g.k != 1 || g.stride != 1 || !g.wt_planes) return false;
+    if (g.Cs != 32 && g.Cs != 64) return false;       // K = 128 needs > 256 VGPRs with two register stages
+    if (g.Cs_valid != g.Cs || g.N > 128) return false;
+    const int n32 = (g.N + 31) / 32 * 32;
+    if (g.Cs * n32 > 8192) return false;
+    if ((unsigned long long)g.M * (unsigned long long)g.lds_ * 4ull >= 0xfffffff0ull) return false;
+    return g.M >= 128 * 1024;
+}
+
+static int dispatch_stream1x1(const ConvGeom& g, hipStream_t st, int* nparts) {
+    const int nt = (g.N + 31) / 32;
+    switch (g.Cs / 16 * 10 + nt) {
+        case 21: return launch_stream1x1<2, 1>(g, st, nparts);
+        case 22: return launch_stream1x1<2, 2>(g, st, nparts);
+        case 23: case 24: return launch_stream1x1<2, 4>(g, st, nparts);
+        case 41: return launch_stream1x1<4, 1>(g, st, nparts);
+        case 42: return launch_stream1x1<4, 2>(g, st, nparts);
+        case 43: case 44: return launch_stream1x1<4, 4>(g, st, nparts);
+        default: return Y4_ERR_SHAPE;
+    }
+}
+
+
 template <bool TR>
-int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
-    if (bm_used) *bm_used = 128;
+int dispatch_gather(const ConvGeom& g, hipStream_t st, int* nparts = nullptr) {
+    // *nparts: number of BN-statistics partial rows the launch writes (M tiles, or blocks of the streaming kernel)
+    if (nparts) *nparts = (g.M + 127) / 128;
+    if (stream1x1_ok(g)) return dispatch_stream1x1(g, st, nparts);
     if (g_conv_mode == 1 || g_conv_mode == 2) {
         const bool one = g_conv_mode == 2;
         if (g.N > 64) {
@@ -738,7 +923,7 @@ int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
             const double c128 = (double)((b128 + 511) / 512) * 128.0;
             const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.10;
             if (c64 < c128 && !(TR && g.stride == 2)) {
-                if (bm_used) *bm_used = 64;
+                if (nparts) *nparts = (g.M + 63) / 64;
                 return one ? launch_gather<64, 128, 2, 2, TR, 32, 1>(g, st) : launch_gather<64, 128, 2, 2, TR, 32, 3>(g, st);
             }
             return one ? launch_gather<128, 128, 2, 2, TR, 32, 1>(g, st) : launch_gather<128, 128, 2, 2, TR, 32, 3>(g, st);
@@ -759,7 +944,7 @@ int dispatch_gather(const ConvGeom& g, hipStream_t st, int* bm_used = nullptr) {
         const double c128 = (double)((b128 + slots - 1) / slots) * 128.0;
         const double c64 = (double)((b64 + slots - 1) / slots) * 64.0 * 1.08;
         if (c64 < c128 && !(TR && g.stride == 2)) {
-            if (bm_used) *bm_used = 64;
+            if (nparts) *nparts = (g.M + 63) / 64;
             return short_k ? launch_gather<64, 128, 2, 2, TR, 16>(g, st) : launch_gather<64, 128, 2, 2, TR>(g, st);
         }
         return short_k ? launch_gather<128, 128, 2, 2, TR, 16>(g, st) : launch_gather<128, 128, 2, 2, TR>(g, st);
@@ -1390,7 +1575,7 @@ int y4_set_workspace(void* ptr, size_t bytes) {
 static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
                          const float* scale, const float* shift, int act,
-                         const float* residual, int ldr, float* stats, int* bm_used, void* stream) {
+                         const float* residual, int ldr, float* stats, int* nparts, void* stream) {
     if (!x || !w || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1418,7 +1603,7 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
         Y4_CHECK_LAUNCH();
         g.wt_planes = planes;
     }
-    return dispatch_gather<false>(g, y4_stream(stream), bm_used);
+    return dispatch_gather<false>(g, y4_stream(stream), nparts);
 }
 
 int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
@@ -1442,13 +1627,11 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
                               float* partials, size_t partial_bytes, long long* nparts_host, void* stream) {
     if (!partials || !nparts_host) return Y4_ERR_NULL;
     if (partial_bytes < y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;
-    int bm = 128;
+    int np = 0;
     const int rc = conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, nullptr, nullptr, Y4_ACT_LINEAR,
-                                 nullptr, 0, partials, &bm, stream);
+                                 nullptr, 0, partials, &np, stream);
     if (rc != Y4_OK) return rc;
-    const int pad = (k - 1) / 2;
-    const long long M = (long long)B * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-    *nparts_host = (M + bm - 1) / bm;
+    *nparts_host = np;
     return Y4_OK;
 }
 

@@ -81,9 +81,11 @@ __global__ __launch_bounds__(PW_THREADS) void bn_stats_kernel(const float* __res
 }
 
 // stage 2 of every per-channel reduction: partial rows [nparts][2][C] (fp32, each a sum over a few
-// thousand pixels at most) -> acc[2][C] in fp64.  <= 64 blocks, so the fp64 atomics do not contend.
+// thousand pixels at most) -> bacc[gridDim][2][C] in fp64, one row per block (<= FOLD_BLOCKS); the finalize
+// kernels add those rows in index order, so the whole reduction is deterministic and needs no memset.
+constexpr int FOLD_BLOCKS = 64;
 __global__ __launch_bounds__(PW_THREADS) void fold_partials_kernel(const float* __restrict__ part, long long nparts,
-                                                                   int C2, double* __restrict__ acc) {
+                                                                   int C2, double* __restrict__ bacc) {
     const long long per = (nparts + gridDim.x - 1) / gridDim.x;
     const long long p0 = (long long)blockIdx.x * per;
     long long p1 = p0 + per;
@@ -96,18 +98,20 @@ __global__ __launch_bounds__(PW_THREADS) void fold_partials_kernel(const float* 
             s2 += (double)part[(p + 2) * C2 + c]; s3 += (double)part[(p + 3) * C2 + c];
         }
         for (; p < p1; ++p) s0 += (double)part[p * C2 + c];
-        if (p1 > p0) atomicAdd(&acc[c], (s0 + s1) + (s2 + s3));
+        bacc[(long long)blockIdx.x * C2 + c] = (s0 + s1) + (s2 + s3);
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ acc, long long M, int C, float eps, float momentum,
+__global__ void bn_finalize_kernel(const double* __restrict__ bacc, int nb, long long M, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ invstd,
                                    float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && nbt) *nbt += 1;
     if (c >= C) return;
-    const double mu = acc[c] / (double)M;
-    double var = acc[C + c] / (double)M - mu * mu;
+    double s = 0, ss = 0;
+    for (int b = 0; b < nb; ++b) { s += bacc[(long long)b * 2 * C + c]; ss += bacc[(long long)b * 2 * C + C + c]; }
+    const double mu = s / (double)M;
+    double var = ss / (double)M - mu * mu;
     if (var < 0) var = 0;
     mean[c] = (float)mu;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -197,12 +201,15 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ acc, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ bacc, int nb, int C, double* __restrict__ acc,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    dbeta[c] = (float)acc[c];
-    dgamma[c] = (float)acc[C + c];
+    double s = 0, ss = 0;
+    for (int b = 0; b < nb; ++b) { s += bacc[(long long)b * 2 * C + c]; ss += bacc[(long long)b * 2 * C + C + c]; }
+    acc[c] = s; acc[C + c] = ss;                       // read by the apply pass
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)ss;
 }
 
 // backward pass 2: dy = gamma*invstd * (g - sum_g/M - xhat * sum_gx/M)
@@ -424,13 +431,21 @@ static long long bn_blocks(long long M, int C) {
 // [2C doubles][blocks * 2C floats]
 size_t y4_bn_workspace(long long M, int C) {
     if (M <= 0 || C <= 0) return 0;
-    return (size_t)2 * C * sizeof(double) + (size_t)bn_blocks(M, C) * 2 * C * sizeof(float);
+    return y4_bn_finalize_workspace(C) + (size_t)bn_blocks(M, C) * 2 * C * sizeof(float);
 }
-static int fold_partials(const float* part, long long nparts, int C, double* acc, hipStream_t st) {
-    if (hipMemsetAsync(acc, 0, (size_t)2 * C * sizeof(double), st) != hipSuccess) return Y4_ERR_LAUNCH;
-    int blocks = (int)(nparts < 64 ? nparts : 64);
+// workspace head: acc[2C] | bacc[FOLD_BLOCKS][2C] doubles
+size_t y4_bn_finalize_workspace(int C) {
+    return C > 0 ? (size_t)(1 + FOLD_BLOCKS) * 2 * C * sizeof(double) : 0;
+}
+static int fold_partials(const float* part, long long nparts, int C, double* bacc, int* nb, hipStream_t st) {
+    int blocks = (int)(nparts < FOLD_BLOCKS ? nparts : FOLD_BLOCKS);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(blocks), dim3(PW_THREADS), 0, st, part, nparts, 2 * C, acc);
+    // every block gets at least one row: per = ceil(nparts / blocks) may leave trailing blocks empty -> shrink
+    const long long per = (nparts + blocks - 1) / blocks;
+    blocks = (int)((nparts + per - 1) / per);
+    if (blocks < 1) blocks = 1;
+    *nb = blocks;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(blocks), dim3(PW_THREADS), 0, st, part, nparts, 2 * C, bacc);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -443,15 +458,17 @@ int y4_bn_stats_f32(const float* y, int ldy, long long M, int C, float* mean, fl
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
     double* acc = static_cast<double*>(workspace);
-    float* part = reinterpret_cast<float*>(acc + 2 * C);
+    double* bacc = acc + 2 * C;
+    float* part = reinterpret_cast<float*>(acc + (size_t)(1 + FOLD_BLOCKS) * 2 * C);
     const RowMap rm = row_map(C);
     const int nrows = stat_rows(M, rm.rpb);
     const long long blocks = bn_blocks(M, C);
     hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, y, (long long)ldy, M, C,
                        rm.tpr, rm.rpb, nrows, part);
     Y4_CHECK_LAUNCH();
-    { const int rc = fold_partials(part, blocks, C, acc, st); if (rc != Y4_OK) return rc; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, M, C, eps, momentum, mean,
+    int nb = 0;
+    { const int rc = fold_partials(part, blocks, C, bacc, &nb, st); if (rc != Y4_OK) return rc; }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bacc, nb, M, C, eps, momentum, mean,
                        invstd, running_mean, running_var, num_batches_tracked);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -463,11 +480,12 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
                                 void* workspace, size_t workspace_bytes, void* stream) {
     if (!partials || !mean || !invstd || !workspace) return Y4_ERR_NULL;
     if (nparts <= 0 || M <= 0 || C <= 0) return Y4_ERR_SHAPE;
-    if (workspace_bytes < (size_t)2 * C * sizeof(double)) return Y4_ERR_WORKSPACE;
+    if (workspace_bytes < y4_bn_finalize_workspace(C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
-    double* acc = static_cast<double*>(workspace);
-    { const int rc = fold_partials(partials, nparts, C, acc, st); if (rc != Y4_OK) return rc; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, M, C, eps, momentum, mean,
+    double* bacc = static_cast<double*>(workspace) + 2 * C;
+    int nb = 0;
+    { const int rc = fold_partials(partials, nparts, C, bacc, &nb, st); if (rc != Y4_OK) return rc; }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bacc, nb, M, C, eps, momentum, mean,
                        invstd, running_mean, running_var, num_batches_tracked);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -499,15 +517,17 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
     double* acc = static_cast<double*>(workspace);
-    float* part = reinterpret_cast<float*>(acc + 2 * C);
+    double* bacc = acc + 2 * C;
+    float* part = reinterpret_cast<float*>(acc + (size_t)(1 + FOLD_BLOCKS) * 2 * C);
     const RowMap rm = row_map(C);
     const int nrows = stat_rows(M, rm.rpb);
     const long long rblocks = bn_blocks(M, C);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((unsigned)rblocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz,
                        y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, nrows, part);
     Y4_CHECK_LAUNCH();
-    { const int rc = fold_partials(part, rblocks, C, acc, st); if (rc != Y4_OK) return rc; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, C, dgamma, dbeta);
+    int nb = 0;
+    { const int rc = fold_partials(part, rblocks, C, bacc, &nb, st); if (rc != Y4_OK) return rc; }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta);
     Y4_CHECK_LAUNCH();
     long long blocks = (M + rm.rpb - 1) / rm.rpb;
     if (blocks > 256 * 16) blocks = 256 * 16;

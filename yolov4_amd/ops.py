@@ -175,10 +175,11 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
         nparts = n.value
     mean = torch.empty(Cout, device=x.device, dtype=torch.float32)
     invstd = torch.empty(Cout, device=x.device, dtype=torch.float32)
-    ws = _ws(2 * Cout * 8, x.device)
+    wsb = L.y4_bn_finalize_workspace(Cout)
+    ws = _ws(wsb, x.device)
     check(L.y4_bn_finalize_partials_f32(_ptr(part), nparts, B * Ho * Wo, Cout, _ptr(mean), _ptr(invstd),
                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), float(momentum), float(eps),
-                                        _ptr(ws), 2 * Cout * 8, _stream()), 'bn_finalize_partials')
+                                        _ptr(ws), wsb, _stream()), 'bn_finalize_partials')
     return y, mean, invstd
 
 
