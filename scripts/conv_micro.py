@@ -16,19 +16,24 @@ SHAPES = [  # Cin, Cout, k, s, H
     (256, 512, 3, 2, 76), (64, 64, 3, 1, 152), (128, 128, 1, 1, 76),
     (64, 64, 1, 1, 152), (32, 64, 3, 1, 304), (64, 32, 1, 1, 304),
     (256, 128, 1, 1, 76), (1024, 512, 1, 1, 19), (256, 256, 1, 1, 38), (128, 64, 1, 1, 304), (512, 512, 1, 1, 19),
+    (3, 32, 3, 1, 608),
 ]
 if only:
     idx = [int(i) for i in only.split(',')]
     SHAPES = [SHAPES[i] for i in idx]
 g = torch.Generator(device='cpu'); g.manual_seed(0)
 for (ci, co, k, s, H) in SHAPES:
-    x = torch.randn((B, ci, H, H), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    x = torch.randn((B, ci, H, H), generator=g).to(dev)
+    if ci != 3:
+        x = x.contiguous(memory_format=torch.channels_last)
     w = (torch.randn((co, ci, k, k), generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
     Ho = (H + 2 * ((k - 1) // 2) - k) // s + 1
     dy = torch.randn((B, co, Ho, Ho), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     fl = 2.0 * B * Ho * Ho * co * ci * k * k
     res = []
     for kind in kinds:
+        if ci == 3 and kind == 'dgrad':
+            continue
         fn = {'fwd': lambda: ops.conv_fwd_raw(x, w, k, s), 'dgrad': lambda: ops.conv_dgrad_raw(dy, w, (B, ci, H, H), k, s),
               'wgrad': lambda: ops.conv_wgrad_raw(x, dy, (co, ci, k, k), k, s)}[kind]
         fn(); torch.cuda.synchronize()

@@ -1471,6 +1471,123 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemGeom g) {
     }
 }
 
+// Stem forward on the matrix cores (bf16x3 mode): the 27-value patch of a pixel is the A row (K = 27 -> 32,
+// ordered k = r*9 + c*3 + q so that the three q of one (r, c) are neighbours in memory), gathered straight from
+// the strided input into the MFMA A layout (lane = pixel, 2 x 8 k values), split in registers; the filter is
+// 24 VGPRs of B fragments per wave.  12 MFMAs per 32 pixels x 32 channels; the C layout (lane = channel) gives
+// 128-byte contiguous stores.  Persistent blocks walk groups of 256 pixels and leave one BN-statistics row
+// per group (same contract as the VALU kernel above).
+__global__ __launch_bounds__(256) void conv_stem_fwd_bf16x3_kernel(const StemGeom g, const int ngroups, const float inv_hw,
+                                                                   const float inv_w) {
+    __shared__ float sred[4][32][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int HW = g.H * g.W;
+    bf16x8 fb[2][3];
+    int koff[16];          // element offset of k relative to the pixel, per lane
+    int ktap[16];          // r*3+q (bit index into the 9-bit validity mask), 9 = padding k
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = (i >> 3) * 16 + fh * 8 + (i & 7);
+        const int r = k / 9, c = (k - r * 9) / 3, q = k - r * 9 - c * 3;
+        const bool kv = k < 27;
+        koff[i] = kv ? (int)(c * g.sxc + (r - 1) * g.sxh + (q - 1) * g.sxw) * 4 : 0;
+        ktap[i] = kv ? r * 3 + q : 9;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f32x4 w0, w1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = ks * 16 + fh * 8 + i;
+            const int r = k / 9, c = (k - r * 9) / 3, q = k - r * 9 - c * 3;
+            const float v = (k < 27 && fr < g.Cout) ? g.w[fr * 27 + (r * 3 + q) * 3 + c] : 0.f;
+            if (i < 4) w0[i] = v; else w1[i - 4] = v;
+        }
+        u32x2 a1, a2, a3, b1, b2, b3;
+        split3x4(w0, a1, a2, a3);
+        split3x4(w1, b1, b2, b3);
+        const u32x4 q1 = {a1[0], a1[1], b1[0], b1[1]}, q2 = {a2[0], a2[1], b2[0], b2[1]}, q3 = {a3[0], a3[1], b3[0], b3[1]};
+        fb[ks][0] = __builtin_bit_cast(bf16x8, q1); fb[ks][1] = __builtin_bit_cast(bf16x8, q2); fb[ks][2] = __builtin_bit_cast(bf16x8, q3);
+    }
+    const float sc = (g.scale && fr < g.Cout) ? g.scale[fr] : 1.f;
+    const float sh = (g.shift && fr < g.Cout) ? g.shift[fr] : 0.f;
+    const __amdgpu_buffer_rsrc_t rsrc = y4_make_rsrc(g.x, 0xfffffff0u);      // extent checked on the host
+    float xv0[16], xv1[16];
+    auto load = [&](float (&xv)[16], long long tile) {
+        const long long p = tile * 32 + fr;
+        unsigned base = 0xffffffffu;
+        unsigned m9 = 0;
+        if (p < g.M) {
+            int b = (int)((float)p * inv_hw);
+            int rem = (int)(p - (long long)b * HW);
+            if (rem < 0) { --b; rem += HW; } else if (rem >= HW) { ++b; rem -= HW; }
+            int h = (int)((float)rem * inv_w);
+            int w = rem - h * g.W;
+            if (w < 0) { --h; w += g.W; } else if (w >= g.W) { ++h; w -= g.W; }
+            base = (unsigned)(b * g.sxb + h * g.sxh + w * g.sxw) * 4u;
+            const unsigned hm = (h > 0 ? 1u : 0u) | 2u | (h + 1 < g.H ? 4u : 0u);
+            const unsigned wm = (w > 0 ? 1u : 0u) | 2u | (w + 1 < g.W ? 4u : 0u);
+            m9 = ((hm & 1u) ? wm : 0u) | ((hm & 2u) ? wm << 3 : 0u) | ((hm & 4u) ? wm << 6 : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool ok = (m9 >> ktap[i]) & 1u;
+            xv[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, ok ? (int)(base + (unsigned)koff[i]) : -1, 0, 0));
+        }
+    };
+    float cs = 0.f, css = 0.f;
+    auto compute = [&](float (&xv)[16], long long tile) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f32x4 v0 = {xv[ks * 8 + 0], xv[ks * 8 + 1], xv[ks * 8 + 2], xv[ks * 8 + 3]};
+            const f32x4 v1 = {xv[ks * 8 + 4], xv[ks * 8 + 5], xv[ks * 8 + 6], xv[ks * 8 + 7]};
+            u32x2 a1, a2, a3, b1, b2, b3;
+            split3x4(v0, a1, a2, a3);
+            split3x4(v1, b1, b2, b3);
+            const u32x4 q1 = {a1[0], a1[1], b1[0], b1[1]}, q2 = {a2[0], a2[1], b2[0], b2[1]}, q3 = {a3[0], a3[1], b3[0], b3[1]};
+            const bf16x8 f1 = __builtin_bit_cast(bf16x8, q1), f2 = __builtin_bit_cast(bf16x8, q2), f3 = __builtin_bit_cast(bf16x8, q3);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f3, fb[ks][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, fb[ks][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, fb[ks][2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2, fb[ks][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, fb[ks][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, fb[ks][0], acc, 0, 0, 0);
+        }
+        const long long mbase = tile * 32 + 4 * fh;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float raw = acc[e];
+            cs += raw; css += raw * raw;                  // pixels past M contribute exact zeros
+            const long long m = mbase + (e & 3) + 8 * (e >> 2);
+            if (fr < g.Cout && m < g.M) g.y[m * g.ldy + fr] = y4_act(raw * sc + sh, g.act);
+        }
+    };
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const long long t0 = (long long)grp * 8 + wave * 2;
+        load(xv0, t0);
+        load(xv1, t0 + 1);
+        cs = 0.f; css = 0.f;
+        compute(xv0, t0);
+        compute(xv1, t0 + 1);
+        if (g.stats) {
+            cs += __shfl_xor(cs, 32, 64);
+            css += __shfl_xor(css, 32, 64);
+            if (fh == 0) { sred[wave][fr][0] = cs; sred[wave][fr][1] = css; }
+            __syncthreads();
+            if (tid < 64) {
+                const int c = tid & 31, which = tid >> 5;
+                const float t = (sred[0][c][which] + sred[1][c][which]) + (sred[2][c][which] + sred[3][c][which]);
+                if (c < g.Cout) g.stats[((long long)grp * 2 + which) * g.Cout + c] = t;
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // wgrad of the stem: D[n][j] (32 x 27->32) = sum_p dy[p][n] * x[p + tap(j)][c(j)], operands
 // straight from global memory into the MFMA (a dy pixel row IS the 32-float A fragment).
 struct StemWgradGeom {
@@ -1502,20 +1619,31 @@ __global__ __launch_bounds__(256) void conv_stem_wgrad_kernel(const StemWgradGeo
         const int rem = (int)(p - (long long)b * g.H * g.W);
         h = rem / g.W; w = rem - h * g.W;
     }
-    const float* dyp = g.dy + p * g.lddy + fr;
+    // 8 pixel pairs per trip: 16 independent buffer loads (out-of-range / halo lanes read zeros through the
+    // descriptor's bounds check) are in flight before the 8 MFMAs consume them -- the loop is latency-bound otherwise
+    const long long dy_first = p_begin < g.M ? p_begin : 0;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = y4_make_rsrc(g.dy + dy_first * g.lddy, (unsigned)(g.pix_per_wave * g.lddy * 4));
+    const __amdgpu_buffer_rsrc_t x_rsrc = y4_make_rsrc(g.x, 0xfffffff0u);                     // extent checked on the host
+    const unsigned dy_step = (unsigned)g.lddy * 8u;                                            // 2 pixels
+    unsigned dy_off = ((unsigned)fh * (unsigned)g.lddy + (unsigned)fr) * 4u;
     const long long coff = c * g.sxc;
-    for (; p < p_end + fh; p += 2) {                                 // both halves iterate the same count
-        float a = 0.f, bv = 0.f;
-        if (p < p_end) {
-            if (nok) a = *dyp;
+    for (long long pc = p_begin; pc < p_end; pc += 16) {
+        float a[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool pok = p < p_end;
             const int hi = h + r, wi = w + q;
-            if (jok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
-                bv = g.x[b * g.sxb + coff + hi * g.sxh + wi * g.sxw];
+            const bool xok = pok && jok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            const unsigned xo = (unsigned)(b * g.sxb + coff + hi * g.sxh + wi * g.sxw) * 4u;
+            a[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dy_rsrc, (pok && nok) ? (int)dy_off : -1, 0, 0));
+            bv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x_rsrc, xok ? (int)xo : -1, 0, 0));
+            dy_off += dy_step;
+            p += 2;
+            w += 2;
+            if (w >= g.W) { w -= g.W; if (++h == g.H) { h = 0; ++b; } }  // W >= 2
         }
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
-        dyp += 2 * g.lddy;
-        w += 2;
-        if (w >= g.W) { w -= g.W; if (++h == g.H) { h = 0; ++b; } }  // W >= 2
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], bv[u], acc, 0, 0, 0);
     }
     float* out = g.slabs + wave_id * 1024;     // [32 n][32 j]
 #pragma unroll
@@ -1758,6 +1886,17 @@ int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long lo
     g.M = (long long)B * H * W;
     const long long blocks = (g.M + 255) / 256;
     if (blocks >= (1ll << 31)) return Y4_ERR_SHAPE;
+    // matrix-core variant: bf16x3 arithmetic, 32-bit byte offsets into x (non-negative strides)
+    const bool mfma_ok = g_conv_mode == 1 && sxb >= 0 && sxc >= 0 && sxh >= 0 && sxw >= 0 &&
+                         ((long long)(B - 1) * sxb + 2 * sxc + (long long)(H - 1) * sxh + (long long)(W - 1) * sxw + 1) * 4 < 0xfffffff0ll &&
+                         (long long)H * W < (1 << 24);
+    if (mfma_ok) {
+        const int grid = (int)(blocks < 2048 ? blocks : 2048);
+        hipLaunchKernelGGL(conv_stem_fwd_bf16x3_kernel, dim3(grid), dim3(256), 0, y4_stream(stream), g, (int)blocks,
+                           1.0f / (float)((long long)H * W), 1.0f / (float)W);
+        Y4_CHECK_LAUNCH();
+        return Y4_OK;
+    }
     hipLaunchKernelGGL(conv_stem_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, y4_stream(stream), g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1779,7 +1918,10 @@ int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long 
     g.B = B; g.H = H; g.W = W; g.Cout = Cout;
     g.M = (long long)B * H * W;
     long long ppw = (g.M + STEM_WAVES - 1) / STEM_WAVES;
-    ppw = (ppw + 1) & ~1ll;                       // even, so MFMA pixel pairs never straddle waves
+    ppw = (ppw + 15) & ~15ll;                     // 16-pixel trips (8 MFMA pixel pairs) never straddle waves
+    if ((long long)ppw * lddy * 4 >= 0xfffffff0ll || sxb < 0 || sxc < 0 || sxh < 0 || sxw < 0 ||
+        ((long long)(B - 1) * sxb + 2 * sxc + (long long)(H - 1) * sxh + (long long)(W - 1) * sxw + 1) * 4 >= 0xfffffff0ll)
+        return Y4_ERR_SHAPE;
     g.pix_per_wave = ppw;
     hipStream_t st = y4_stream(stream);
     hipLaunchKernelGGL(conv_stem_wgrad_kernel, dim3(STEM_WAVES / 4), dim3(256), 0, st, g);
