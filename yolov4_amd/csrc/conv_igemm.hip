@@ -1307,6 +1307,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3(const WgradGeom g) {
     }
 }
 
+// vector variant: a block owns VEC float4 columns; its 256/VEC thread groups each add every (256/VEC)-th slab
+// (4 independent loads in flight), then the groups are combined through LDS in group order -- a fixed
+// summation tree for a given split count, hence deterministic, and hundreds of slabs no longer serialise
+// behind one thread's load latency.
+template <int VEC>
+__global__ __launch_bounds__(256) void slab_reduce_vec_kernel(const f32x4* __restrict__ slabs, f32x4* __restrict__ out,
+                                                              long long nvec, int splits) {
+    constexpr int SG = 256 / VEC;
+    __shared__ f32x4 red[SG][VEC];
+    const int v = threadIdx.x % VEC, sg = threadIdx.x / VEC;
+    const long long i = (long long)blockIdx.x * VEC + v;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (i < nvec) {
+        int k = sg;
+        for (; k + 3 * SG < splits; k += 4 * SG) {
+            const f32x4 a = slabs[(long long)k * nvec + i], b = slabs[(long long)(k + SG) * nvec + i];
+            const f32x4 c = slabs[(long long)(k + 2 * SG) * nvec + i], d = slabs[(long long)(k + 3 * SG) * nvec + i];
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; k < splits; k += SG) s0 += slabs[(long long)k * nvec + i];
+    }
+    red[sg][v] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sg == 0 && i < nvec) {
+        f32x4 t = red[0][v];
+#pragma unroll
+        for (int g = 1; g < SG; ++g) t += red[g][v];
+        out[i] = t;
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                    long long n, int splits) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
@@ -1865,9 +1896,19 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
     if (rc != Y4_OK) return rc;
     if (g.splits > 1) {
         const long long n = (long long)Cout * g.J;
-        const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st,
-                           static_cast<const float*>(workspace), dw, n, g.splits);
+        if ((n & 3) == 0 && !(reinterpret_cast<uintptr_t>(dw) & 15) && !(reinterpret_cast<uintptr_t>(workspace) & 15)) {
+            const long long nvec = n / 4;
+            if (nvec >= 64 * 1024)
+                hipLaunchKernelGGL(slab_reduce_vec_kernel<64>, dim3((unsigned)((nvec + 63) / 64)), dim3(256), 0, st,
+                                   static_cast<const f32x4*>(workspace), reinterpret_cast<f32x4*>(dw), nvec, g.splits);
+            else
+                hipLaunchKernelGGL(slab_reduce_vec_kernel<16>, dim3((unsigned)((nvec + 15) / 16)), dim3(256), 0, st,
+                                   static_cast<const f32x4*>(workspace), reinterpret_cast<f32x4*>(dw), nvec, g.splits);
+        } else {
+            const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st,
+                               static_cast<const float*>(workspace), dw, n, g.splits);
+        }
         Y4_CHECK_LAUNCH();
     }
     return Y4_OK;

@@ -83,33 +83,69 @@ __global__ __launch_bounds__(PW_THREADS) void bn_stats_kernel(const float* __res
 // stage 2 of every per-channel reduction: partial rows [nparts][2][C] (fp32, each a sum over a few
 // thousand pixels at most) -> bacc[gridDim][2][C] in fp64, one row per block (<= FOLD_BLOCKS); the finalize
 // kernels add those rows in index order, so the whole reduction is deterministic and needs no memset.
-constexpr int FOLD_BLOCKS = 64;
+// Threads are laid out [row group][column] so that narrow layers (2C < 256) still use the whole block, and
+// every thread keeps 8 independent loads in flight (the loop is latency-bound otherwise).
+constexpr int FOLD_BLOCKS = 256;
 __global__ __launch_bounds__(PW_THREADS) void fold_partials_kernel(const float* __restrict__ part, long long nparts,
-                                                                   int C2, double* __restrict__ bacc) {
+                                                                   int C2, int cw, double* __restrict__ bacc) {
+    __shared__ double red[PW_THREADS];
     const long long per = (nparts + gridDim.x - 1) / gridDim.x;
     const long long p0 = (long long)blockIdx.x * per;
     long long p1 = p0 + per;
     if (p1 > nparts) p1 = nparts;
-    for (int c = threadIdx.x; c < C2; c += blockDim.x) {
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        long long p = p0;
-        for (; p + 3 < p1; p += 4) {
-            s0 += (double)part[p * C2 + c]; s1 += (double)part[(p + 1) * C2 + c];
-            s2 += (double)part[(p + 2) * C2 + c]; s3 += (double)part[(p + 3) * C2 + c];
+    const int rg_n = PW_THREADS / cw;                      // row groups (cw = power of two <= 256)
+    const int col = threadIdx.x % cw, rg = threadIdx.x / cw;
+    for (int c0 = 0; c0 < C2; c0 += cw) {
+        const int c = c0 + col;
+        double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (c < C2) {
+            long long p = p0 + rg;
+            for (; p + 7ll * rg_n < p1; p += 8ll * rg_n) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = part[(p + (long long)u * rg_n) * C2 + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += (double)v[u];
+            }
+            for (; p < p1; p += rg_n) s[0] += (double)part[p * C2 + c];
         }
-        for (; p < p1; ++p) s0 += (double)part[p * C2 + c];
-        bacc[(long long)blockIdx.x * C2 + c] = (s0 + s1) + (s2 + s3);
+        red[threadIdx.x] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+        __syncthreads();
+        if (rg == 0 && c < C2) {
+            double t = red[col];
+            for (int g = 1; g < rg_n; ++g) t += red[g * cw + col];
+            bacc[(long long)blockIdx.x * C2 + c] = t;
+        }
+        __syncthreads();
     }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ bacc, int nb, long long M, int C, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ invstd,
-                                   float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) *nbt += 1;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int b = 0; b < nb; ++b) { s += bacc[(long long)b * 2 * C + c]; ss += bacc[(long long)b * 2 * C + C + c]; }
+// sums column c of the <= FOLD_BLOCKS fp64 rows: 8 threads per column (independent loads), combined in LDS
+__device__ __forceinline__ void fold_rows32(const double* __restrict__ bacc, int nb, int C, int c0, double (&red)[2][8][32],
+                                            double& s, double& ss) {
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;           // 256 threads = 8 groups x 32 channels
+    const int c = c0 + cl;
+    double a = 0, b2 = 0;
+    if (c < C)
+        for (int r = g; r < nb; r += 8) { a += bacc[(long long)r * 2 * C + c]; b2 += bacc[(long long)r * 2 * C + C + c]; }
+    red[0][g][cl] = a; red[1][g][cl] = b2;
+    __syncthreads();
+    s = 0; ss = 0;
+    if (g == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s += red[0][k][cl]; ss += red[1][k][cl]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ bacc, int nb, long long M, int C, float eps,
+                                                          float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ rmean, float* __restrict__ rvar, long long* nbt) {
+    __shared__ double red[2][8][32];
+    double s, ss;
+    fold_rows32(bacc, nb, C, blockIdx.x * 32, red, s, ss);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) *nbt += 1;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
     const double mu = s / (double)M;
     double var = ss / (double)M - mu * mu;
     if (var < 0) var = 0;
@@ -201,12 +237,14 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ bacc, int nb, int C, double* __restrict__ acc,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0, ss = 0;
-    for (int b = 0; b < nb; ++b) { s += bacc[(long long)b * 2 * C + c]; ss += bacc[(long long)b * 2 * C + C + c]; }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ bacc, int nb, int C,
+                                                              double* __restrict__ acc, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    __shared__ double red[2][8][32];
+    double s, ss;
+    fold_rows32(bacc, nb, C, blockIdx.x * 32, red, s, ss);
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    if ((threadIdx.x >> 5) != 0 || c >= C) return;
     acc[c] = s; acc[C + c] = ss;                       // read by the apply pass
     dbeta[c] = (float)s;
     dgamma[c] = (float)ss;
@@ -438,14 +476,18 @@ size_t y4_bn_finalize_workspace(int C) {
     return C > 0 ? (size_t)(1 + FOLD_BLOCKS) * 2 * C * sizeof(double) : 0;
 }
 static int fold_partials(const float* part, long long nparts, int C, double* bacc, int* nb, hipStream_t st) {
-    int blocks = (int)(nparts < FOLD_BLOCKS ? nparts : FOLD_BLOCKS);
+    // >= 16 rows per block; every block gets at least one row (per = ceil(nparts / blocks) may leave trailing
+    // blocks empty -> shrink)
+    long long want = (nparts + 15) / 16;
+    int blocks = (int)(want < FOLD_BLOCKS ? want : FOLD_BLOCKS);
     if (blocks < 1) blocks = 1;
-    // every block gets at least one row: per = ceil(nparts / blocks) may leave trailing blocks empty -> shrink
     const long long per = (nparts + blocks - 1) / blocks;
     blocks = (int)((nparts + per - 1) / per);
     if (blocks < 1) blocks = 1;
     *nb = blocks;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(blocks), dim3(PW_THREADS), 0, st, part, nparts, 2 * C, bacc);
+    int cw = 32;
+    while (cw < 2 * C && cw < PW_THREADS) cw *= 2;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(blocks), dim3(PW_THREADS), 0, st, part, nparts, 2 * C, cw, bacc);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -468,7 +510,7 @@ int y4_bn_stats_f32(const float* y, int ldy, long long M, int C, float* mean, fl
     Y4_CHECK_LAUNCH();
     int nb = 0;
     { const int rc = fold_partials(part, blocks, C, bacc, &nb, st); if (rc != Y4_OK) return rc; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bacc, nb, M, C, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, M, C, eps, momentum, mean,
                        invstd, running_mean, running_var, num_batches_tracked);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -485,7 +527,7 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
     double* bacc = static_cast<double*>(workspace) + 2 * C;
     int nb = 0;
     { const int rc = fold_partials(partials, nparts, C, bacc, &nb, st); if (rc != Y4_OK) return rc; }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bacc, nb, M, C, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, M, C, eps, momentum, mean,
                        invstd, running_mean, running_var, num_batches_tracked);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -527,7 +569,7 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
     Y4_CHECK_LAUNCH();
     int nb = 0;
     { const int rc = fold_partials(part, rblocks, C, bacc, &nb, st); if (rc != Y4_OK) return rc; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta);
     Y4_CHECK_LAUNCH();
     long long blocks = (M + rm.rpb - 1) / rm.rpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
