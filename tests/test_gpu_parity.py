@@ -580,6 +580,46 @@ def test_wgrad_on_side_stream_is_identical(dev, golden, hip_model):
         assert torch.equal(grads[False][k], grads[True][k]), k
 
 
+def test_ddp_grad_slots_written_in_place(dev, golden, hip_model):
+    """BucketedDDP (single process, no process group): filter gradients are written by the wgrad kernel straight
+    into the flat bucket slots; result must equal plain autograd accumulation, also over a 2-step window."""
+    from yolov4_amd.ddp import BucketedDDP
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    m = hip_model
+    _reset(m, golden)
+    m.train()
+    x = recipe.randn((2, 3, 128, 128), 80).to(dev)
+    labels = recipe.synth_labels(2, 128, 81, counts=[9, 21])
+    crit = YOLOLoss(CFG, ignore_thresh=0.7, device=dev, mutate_outputs=False)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m.zero_grad(set_to_none=True)
+    for _ in range(2):
+        crit(m(x), {'padded_labels': labels}).backward()
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.load_state_dict(sd)
+    ddp = BucketedDDP(m)
+    try:
+        ddp.zero_grad()
+        ddp.accumulating = True
+        crit(ddp(x), {'padded_labels': labels}).backward()
+        ddp.finish_backward()
+        ddp.accumulating = False
+        ddp.rearm()
+        crit(ddp(x), {'padded_labels': labels}).backward()
+        ddp.finish_backward()
+        for k, p in m.named_parameters():
+            assert p.grad.data_ptr() >= 0 and torch.equal(p.grad, ref[k]), k
+        assert all(b.pending == 0 for b in ddp.buckets)
+    finally:
+        for h in ddp._hooks:
+            h.remove()
+        for p in m.parameters():
+            p.grad = None
+            for a in ('_y4_grad_fresh', '_y4_grad_ready'):
+                if hasattr(p, a):
+                    delattr(p, a)
+
+
 def test_gradients_within_reference_rounding(dev, golden, hip_model):
     """Same linear functional of the head logits on three backends: CPU fp64 (truth), CPU fp32 (the
     reference's arithmetic: torch ATen), HIP fp32.  The HIP path must be as close to the truth as the

@@ -124,6 +124,9 @@ class BucketedDDP(torch.nn.Module):
     def zero_grad(self, set_to_none=False):
         for b in self.buckets:
             b.flat.zero_()
+            for p in b.params:
+                # a zeroed slot may be written in place by the producing kernel (yolov4_amd.ops.ConvBNActFn)
+                p._y4_grad_fresh = p.dim() == 4 and p.grad is not None
         self.rearm()
 
     def rearm(self):

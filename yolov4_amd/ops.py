@@ -197,12 +197,22 @@ def conv_dgrad_raw(dy, w, x_shape, k, s):
     return dx
 
 
-def conv_wgrad_raw(x, dy, w_shape, k, s):
+def _is_krsc_dense(t):
+    Co, Ci, kh, kw = t.shape
+    return t.dtype == torch.float32 and t.stride() == (kh * kw * Ci, 1, kw * Ci, Ci)
+
+
+def conv_wgrad_raw(x, dy, w_shape, k, s, out=None):
+    """out: optional fp32 tensor of shape w_shape whose memory is dense KRSC (e.g. a gradient slot of a flat
+    DDP bucket): the kernel then writes the filter gradient in place."""
     L = lib()
     B, Cin, H, W = x.shape
     Cout = w_shape[0]
-    dw = torch.empty(w_shape, device=dy.device, dtype=torch.float32).contiguous(memory_format=CL)
-    dw = krsc(dw)
+    if out is not None and tuple(out.shape) == tuple(w_shape) and _is_krsc_dense(out) and out.data_ptr() % 16 == 0:
+        dw = out
+    else:
+        dw = torch.empty(w_shape, device=dy.device, dtype=torch.float32).contiguous(memory_format=CL)
+        dw = krsc(dw)
     if Cin == 3:
         dy, lddy = as_nhwc(dy, need_vec4=False)
         nbytes = L.y4_conv2d_stem_wgrad_workspace(B, H, W, Cout)
@@ -416,6 +426,14 @@ class ConvBNActFn(torch.autograd.Function):
             param = cfg.get('weight_param')
             if _ASYNC['on'] and param is not None and param.requires_grad:
                 _wgrad_to_param(x, dy, param, k, s)          # lands in param.grad on the side stream
+            elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
+                # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place
+                # (no temporary, no accumulate pass); the bucket is told directly, autograd gets None
+                param._y4_grad_fresh = False
+                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad)
+                if got is not param.grad:
+                    param.grad.add_(got)
+                param._y4_grad_ready()
             else:
                 dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s)
         dres = dz if ctx.has_res else None
