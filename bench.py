@@ -81,11 +81,11 @@ class ConvTimer:
             Ho, Wo = ops.conv_out_hw(H, W, k, s)
             return 2.0 * B * Ho * Wo * w.shape[0] * Cin * k * k, (Cin, w.shape[0], k, s, H)
 
-        def f_dgrad(dy, w, x_shape, k, s, addend=None):
+        def f_dgrad(dy, w, x_shape, k, s, *a, **kw):
             B, Cout, Ho, Wo = dy.shape
             return 2.0 * B * Ho * Wo * Cout * x_shape[1] * k * k, (x_shape[1], Cout, k, s, x_shape[2])
 
-        def f_wgrad(x, dy, w_shape, k, s):
+        def f_wgrad(x, dy, w_shape, k, s, *a, **kw):
             B, Cout, Ho, Wo = dy.shape
             return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k, (x.shape[1], Cout, k, s, x.shape[2])
 
