@@ -58,6 +58,7 @@ class ConvTimer:
     def __init__(self):
         self.rec = []
         self.on = False
+        self.sym = None
 
     def wrap(self, ops):
         timer = self
@@ -72,21 +73,30 @@ class ConvTimer:
                 out = fn(*a, **kw)
                 e1.record()
                 fl, key = flops_of(*a, **kw)
-                timer.rec.append((kind, fl, e0, e1, key))
+                timer.rec.append((kind, fl, e0, e1, key, timer.sym))
                 return out
             return inner
 
         def f_fwd(x, w, k, s, *a, **kw):
             B, Cin, H, W = x.shape
             Ho, Wo = ops.conv_out_hw(H, W, k, s)
+            timer.sym = gather_symbol(False, B * Ho * Wo, w.shape[0], Cin, Cin, k, s, ops.nhwc_pitch(x) if Cin != 3 else 0)
             return 2.0 * B * Ho * Wo * w.shape[0] * Cin * k * k, (Cin, w.shape[0], k, s, H)
 
         def f_dgrad(dy, w, x_shape, k, s, *a, **kw):
             B, Cout, Ho, Wo = dy.shape
+            cpad = (Cout + 31) // 32 * 32
+            timer.sym = gather_symbol(True, x_shape[0] * x_shape[2] * x_shape[3], x_shape[1], cpad, Cout, k, s,
+                                      max(ops.nhwc_pitch(dy), cpad))
             return 2.0 * B * Ho * Wo * Cout * x_shape[1] * k * k, (x_shape[1], Cout, k, s, x_shape[2])
 
         def f_wgrad(x, dy, w_shape, k, s, *a, **kw):
             B, Cout, Ho, Wo = dy.shape
+            mode = args_conv_mode()
+            kern = 'conv_wgrad_mfma_f32' if mode == 'f32' else 'conv_wgrad_bf16x3'
+            tn, tj = (64 if Cout <= 64 else 128), (64 if k * k * x.shape[1] <= 64 else 128)
+            timer.sym = 'conv_stem_wgrad_kernel' if x.shape[1] == 3 else \
+                f'{kern}<{tn}, {tj}' + ('>' if mode == 'f32' else (', 1>' if mode == 'bf16' else ', 3>'))
             return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k, (x.shape[1], Cout, k, s, x.shape[2])
 
         ops.conv_fwd_raw = bracket(ops.conv_fwd_raw, 'conv_fwd', f_fwd)
@@ -94,9 +104,19 @@ class ConvTimer:
         ops.conv_dgrad_raw = bracket(ops.conv_dgrad_raw, 'conv_dgrad', f_dgrad)
         ops.conv_wgrad_raw = bracket(ops.conv_wgrad_raw, 'conv_wgrad', f_wgrad)
 
+    def by_symbol(self):
+        """Seconds / flop / launches per kernel symbol (the names rocprofv3 --stats prints)."""
+        agg = {}
+        for kind, fl, e0, e1, key, sym in self.rec:
+            a = agg.setdefault(sym, [0.0, 0.0, 0])
+            a[0] += fl
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += 1
+        return {k: {'tflops': v[0] / v[1] / 1e12, 'seconds': v[1], 'launches': v[2]} for k, v in agg.items()}
+
     def summary(self):
         agg = {}
-        for kind, fl, e0, e1, _ in self.rec:
+        for kind, fl, e0, e1, _key, _sym in self.rec:
             a = agg.setdefault(kind, [0.0, 0.0, 0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1) * 1e-3
@@ -105,7 +125,7 @@ class ConvTimer:
 
     def table(self, steps):
         agg = {}
-        for kind, fl, e0, e1, key in self.rec:
+        for kind, fl, e0, e1, key, _sym in self.rec:
             a = agg.setdefault((kind,) + key, [0.0, 0.0, 0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1) * 1e-3
@@ -115,6 +135,49 @@ class ConvTimer:
         for (kind, cin, cout, k, s, h), v in rows:
             lines.append(f'{kind:10s} {cin:5d} {cout:5d} {k} {s} {h:4d} {v[2] / steps:7.1f} {v[1] / steps * 1e3:8.2f} {v[0] / v[1] / 1e12:8.1f}')
         return '\n'.join(lines)
+
+
+def gather_symbol(transposed, M, N, Cs, Cs_valid, k, stride, ld):
+    """The kernel symbol dispatch_gather (yolov4_amd/csrc/conv_igemm.hip) launches for this problem -- the same rules,
+    restated so that the roofline block can name ONE kernel as rocprofv3 --stats names it.  M, N = GEMM rows/columns,
+    Cs = channels of the gathered tensor (padded), ld = its pixel pitch."""
+    mode = args_conv_mode()
+    if Cs == 3:
+        return 'conv_stem_fwd_bf16x3_kernel' if mode == 'bf16x3' else 'conv_stem_fwd_kernel'
+    tr = 'true' if transposed else 'false'
+    if (mode == 'bf16x3' and k == 1 and stride == 1 and Cs in (32, 64) and Cs_valid == Cs and N <= 128
+            and Cs * ((N + 31) // 32 * 32) <= 8192 and M * ld * 4 < 0xfffffff0 and M >= 128 * 1024):
+        nt = (N + 31) // 32
+        return f'conv1x1_stream_bf16x3<{Cs // 16}, {4 if nt >= 3 else nt}>'
+    split = mode != 'f32'
+    kern = 'conv_gather_bf16x3' if split else 'conv_gather_mfma_f32'
+    tail = (', 1>' if mode == 'bf16' else ', 3>') if split else None
+    def name(bm, bn, wm, wn, bk=32):
+        return f'{kern}<{bm}, {bn}, {wm}, {wn}, {tr}' + (tail if split else f', {bk}>')
+    if N > 64:
+        nt = (N + 127) // 128
+        b128, b64 = (M + 127) // 128 * nt, (M + 63) // 64 * nt
+        slots = 512 if split or k != 1 else 768
+        c128 = ((b128 + slots - 1) // slots) * 128.0
+        c64 = ((b64 + slots - 1) // slots) * 64.0 * (1.10 if split else 1.08)
+        bk = 16 if (not split and k == 1) else 32
+        if c64 < c128 and not (transposed and stride == 2):
+            return name(64, 128, 2, 2, bk)
+        return name(128, 128, 2, 2, bk)
+    if N > 32:
+        return name(128, 64, 2, 2, 16 if (not split and k == 1) else 32)
+    return name(128, 32, 4, 1)
+
+
+def pmc_traffic_symbol(sym):
+    """HBM-side bytes per launch for one kernel symbol from the recorded rocprofv3 --pmc passes (see pmc_traffic)."""
+    for name in ('r01_pmc_hbm_traffic_per_kernel_v8.json', 'r01_pmc_hbm_traffic_per_kernel.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if os.path.isfile(path):
+            for k, v in json.load(open(path)).items():
+                if sym in k:
+                    return v['hbm_bytes_per_launch_corrected']
+    return None
 
 
 def pmc_traffic(kind):
@@ -273,16 +336,32 @@ def main():
         }
         if timer.rec:
             summ = timer.summary()
-            dom = max(summ, key=lambda k: summ[k]['seconds'])
+            syms = timer.by_symbol()
+            dsym = max(syms, key=lambda k: syms[k]['seconds'])       # ONE kernel symbol, as rocprofv3 --stats names it
+            fam_of = {'conv_wgrad': 'conv_wgrad', 'conv_stem_wgrad': 'conv_wgrad'}
+            dom = next((f for p_, f in fam_of.items() if dsym.startswith(p_)), None) or \
+                ('conv_dgrad' if ', true' in dsym else 'conv_fwd')
             kk = 'mfma_f32' if args.conv_mode == 'f32' else 'bf16x3'
             kname = {'conv_fwd': f'conv_gather_{kk}<..,false> (forward implicit GEMM; filter split, BN-stat fold kernels included)',
                      'conv_dgrad': f'conv_gather_{kk}<..,true> (dgrad implicit GEMM; filter transpose/split included)',
                      'conv_wgrad': f'conv_wgrad_{kk} (+ slab reduce)'}[dom]
-            peak = PEAK_BF16_MFMA_TFLOPS if args.conv_mode == 'bf16' else PEAK_F32_MFMA_TFLOPS
+            # The roofline of the instruction stream that actually runs: bf16x3 spends 6 dense bf16 MFMAs per fp32-exact
+            # product, so its ceiling in ALGORITHMIC flop/s is the bf16 MFMA peak / 6 (= 416.7 TFLOP/s); frac is then the
+            # matrix-pipe utilisation at nominal clock.  (Against the fp32 MFMA peak of 157.3 the same number exceeds 1.)
+            peak = {'bf16': PEAK_BF16_MFMA_TFLOPS, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 6.0, 'f32': PEAK_F32_MFMA_TFLOPS}[args.conv_mode]
+            fam = summ[dom]
+            summ = dict(summ)
+            summ[dom] = dict(fam, tflops=syms[dsym]['tflops'], seconds=syms[dsym]['seconds'], launches=syms[dsym]['launches'])
             out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / peak,
-                               'traffic': pmc_traffic(dom),
-                               'kernel': kname,
+                               'traffic': pmc_traffic_symbol(dsym),
+                               'kernel': dsym,
+                               'peak_note': {'bf16x3': 'dense bf16 MFMA peak 2500 / 6 MFMAs per fp32-exact product',
+                                             'bf16': 'dense bf16 MFMA peak', 'f32': 'dense fp32 MFMA peak'}[args.conv_mode],
+                               'vs_fp32_mfma_peak': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS,
+                               'kernel_note': 'dominant kernel symbol by total time inside the timed steps; the HIP-event bracket '
+                                              'around each launch also covers its filter split / slab-reduce / BN-stat fold '
+                                              'helpers (a few % of the duration); family: ' + kname,
                                'mfma_pipe': ({'instr': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': 6 * summ[dom]['tflops'],
                                               'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': 6 * summ[dom]['tflops'] / PEAK_BF16_MFMA_TFLOPS}
                                              if args.conv_mode == 'bf16x3' else
@@ -294,7 +373,10 @@ def main():
                                'avg_launch_ms': summ[dom]['seconds'] / summ[dom]['launches'] * 1e3,
                                'launches': summ[dom]['launches'],
                                'all_conv_kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['seconds'] / args.steps * 1e3, 2)}
-                                                    for k, v in summ.items()}}
+                                                    for k, v in timer.summary().items()},
+                               'per_symbol': {k: {'tflops': round(v['tflops'], 2), 'avg_launch_ms': round(v['seconds'] / v['launches'] * 1e3, 4),
+                                                  'launches': v['launches']}
+                                              for k, v in sorted(syms.items(), key=lambda kv: -kv[1]['seconds'])}}
         if args.conv_table and timer.rec:
             with open(args.conv_table, 'w') as f:
                 f.write(timer.table(args.steps) + '\n')
