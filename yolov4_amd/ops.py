@@ -354,8 +354,10 @@ def _wgrad_to_param(x, dy, param, k, s):
         side.wait_event(ev)
         dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s)
         if param.grad is None:
+            dw.record_stream(main)          # allocated in the side stream's pool, consumed (and freed) on the main one
             param.grad = dw
         else:
+            param.grad.record_stream(side)
             param.grad.add_(dw)
         ready = getattr(param, '_y4_grad_ready', None)
         if ready is not None:
