@@ -47,9 +47,10 @@ class ConvBNAct(nn.Module):
         self.stride = stride
         self.has_bn = bool(bn)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, out=None):
+        """out: optional destination (a CatBuffer slot) for the activation; the reference has no such argument."""
         n = self.norm
-        cfg = {'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
+        cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training}
         if self.has_bn:
             use_batch_stats = self.training or n.running_mean is None
@@ -106,11 +107,12 @@ class CSPDownSample0(nn.Module):
 
     def forward(self, x):
         xa, xb = ops.fork(self.base(x))
-        x1 = self.part1(xa)
+        cb = ops.cat_buffer(xa, [self.part2_2.conv.out_channels, self.part1.conv.out_channels])
+        x1 = self.part1(xa, out=cb.slot(1))
         ta, tb = ops.fork(self.part2_1_1(xb))
         x2 = self.part2_1_2[1](self.part2_1_2[0](ta), residual=tb)
-        x2 = self.part2_2(x2)
-        return self.transition(ops.cat([x2, x1]))
+        x2 = self.part2_2(x2, out=cb.slot(0))
+        return self.transition(ops.cat([x2, x1], into=cb))
 
 
 class CSPDownSample(nn.Module):
@@ -126,6 +128,7 @@ class CSPDownSample(nn.Module):
 
     def forward(self, x):
         xa, xb = ops.fork(self.base(x))
-        x1 = self.part1(xa)
-        x2 = self.part2(xb)
-        return self.transition(ops.cat([x2, x1]))
+        cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels])
+        x1 = self.part1(xa, out=cb.slot(1))
+        x2 = self.part2[2](self.part2[1](self.part2[0](xb)), out=cb.slot(0))
+        return self.transition(ops.cat([x2, x1], into=cb))

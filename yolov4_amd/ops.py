@@ -244,11 +244,20 @@ def bn_stats_raw(y, running_mean, running_var, nbt, momentum, eps):
     return mean, invstd
 
 
-def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None):
+def _slot_ok(out, shape):
+    """out: a caller-provided destination (typically a channel slice of a concat buffer)."""
+    if out is None:
+        return False
+    ld = nhwc_pitch(out)
+    return (tuple(out.shape) == tuple(shape) and out.dtype == torch.float32 and ld is not None and ld % 4 == 0
+            and out.data_ptr() % 16 == 0)
+
+
+def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None):
     L = lib()
     B, C, H, W = y.shape
     y, ldy = as_nhwc(y)
-    z = empty_nhwc(B, C, H, W, y.device)
+    z = out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual)
@@ -386,12 +395,15 @@ class ConvBNActFn(torch.autograd.Function):
                 raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
             y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
                                                    cfg['nbt'], cfg['momentum'], cfg['eps'])
-            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual)
+            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=cfg.get('out'))
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
         elif bn:
             scale, shift = bn_fold_raw(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
-            z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual)
+            o = cfg.get('out')
+            Ho, Wo = conv_out_hw(x.shape[2], x.shape[3], k, s)
+            z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual,
+                             out=o if _slot_ok(o, (x.shape[0], weight.shape[0], Ho, Wo)) else None)
             ctx.mode = 'bn_eval'
         else:
             z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32)
@@ -465,32 +477,57 @@ def fork(x):
     return Fork2Fn.apply(x)
 
 
+class CatBuffer:
+    """A concat destination allocated BEFORE its inputs are produced: `slot(i)` is the channel slice input i will
+    occupy; a producer that accepts `out=` (ConvBNAct, Upsample) writes there directly and `cat(..., into=)` then
+    has nothing to copy for it (inputs produced elsewhere are copied as usual)."""
+
+    def __init__(self, B, sizes, H, W, device):
+        self.sizes = list(sizes)
+        self.buf = empty_nhwc(B, sum(self.sizes), H, W, device)
+        self.offsets = [sum(self.sizes[:i]) for i in range(len(self.sizes))]
+
+    def slot(self, i):
+        return self.buf[:, self.offsets[i]:self.offsets[i] + self.sizes[i]]
+
+
 class CatFn(torch.autograd.Function):
-    """torch.cat(dim=1): copies into channel slices; backward hands out slice views (zero copy)."""
+    """torch.cat(dim=1): copies into channel slices (skipped for inputs already produced in place, see
+    CatBuffer); backward hands out slice views (zero copy)."""
 
     @staticmethod
-    def forward(ctx, *xs):
+    def forward(ctx, into, *xs):
         B, _, H, W = xs[0].shape
         ctx.sizes = [t.shape[1] for t in xs]
-        out = empty_nhwc(B, sum(ctx.sizes), H, W, xs[0].device)
+        if into is not None and (into.sizes != ctx.sizes or tuple(into.buf.shape) != (B, sum(ctx.sizes), H, W)):
+            into = None
+        out = into.buf if into is not None else empty_nhwc(B, sum(ctx.sizes), H, W, xs[0].device)
         o = 0
         for t in xs:
             _require_gpu(t, 'cat input')
-            copy_into_raw(t, out[:, o:o + t.shape[1]])
+            dst = out[:, o:o + t.shape[1]]
+            if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride()):
+                copy_into_raw(t, dst)
             o += t.shape[1]
         return out
 
     @staticmethod
     def backward(ctx, g):
-        outs, o = [], 0
+        outs, o = [None], 0
         for c in ctx.sizes:
             outs.append(g[:, o:o + c])
             o += c
         return tuple(outs)
 
 
-def cat(xs):
-    return CatFn.apply(*xs)
+def cat(xs, into=None):
+    return CatFn.apply(into, *xs)
+
+
+def cat_buffer(like, sizes, hw=None):
+    """CatBuffer for inputs shaped like `like` ([B, *, H, W]; hw overrides the spatial size)."""
+    H, W = hw if hw is not None else (like.shape[2], like.shape[3])
+    return CatBuffer(like.shape[0], sizes, H, W, like.device)
 
 
 class SppPoolCatFn(torch.autograd.Function):
@@ -563,12 +600,12 @@ class Upsample2xFn(torch.autograd.Function):
     """Upsample.forward, yolo/model/yolov4.py:82-90 (nearest, exact x2)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out=None):
         L = lib()
         _require_gpu(x, 'upsample input')
         B, C, H, W = x.shape
         x, ldx = as_nhwc(x)
-        out = empty_nhwc(B, C, 2 * H, 2 * W, x.device)
+        out = out.t if (out is not None and _slot_ok(out.t, (B, C, 2 * H, 2 * W))) else empty_nhwc(B, C, 2 * H, 2 * W, x.device)
         check(L.y4_upsample2x_fwd_f32(_ptr(x), ldx, _ptr(out), nhwc_pitch(out), B, H, W, C, _stream()), 'upsample')
         ctx.shape = (B, C, H, W)
         return out
@@ -580,7 +617,15 @@ class Upsample2xFn(torch.autograd.Function):
         g, ldg = as_nhwc(g)
         dx = empty_nhwc(B, C, H, W, g.device)
         check(L.y4_upsample2x_bwd_f32(_ptr(g), ldg, _ptr(dx), nhwc_pitch(dx), B, H, W, C, _stream()), 'upsample_bwd')
-        return dx
+        return dx, None
+
+
+class Slot:
+    """Non-tensor wrapper so that a destination slice can be handed to an autograd Function without becoming one of
+    its differentiable inputs."""
+
+    def __init__(self, t):
+        self.t = t
 
 
 # ------------------------------------------------------------------ YOLO head

@@ -62,11 +62,11 @@ class SPPBlock(nn.Module):
 
 class Upsample(nn.Module):
 
-    def forward(self, x, target_size):
+    def forward(self, x, target_size, out=None):
         assert x.dim() == 4
         if target_size[2] != 2 * x.shape[2] or target_size[3] != 2 * x.shape[3]:
             raise ops.Y4Error('Upsample: only the exact x2 nearest case of the YOLOv4 neck is implemented')
-        return ops.Upsample2xFn.apply(x)
+        return ops.Upsample2xFn.apply(x, ops.Slot(out) if out is not None else None)
 
 
 class FPNBlock(nn.Module):
@@ -86,15 +86,17 @@ class FPNBlock(nn.Module):
     def forward(self, x3, x4, x5):
         f3 = self.module1(x5)
         f3a, f3b = ops.fork(f3)
-        up = self.upsample1(self.conv3(f3a), x4.size())
-        x4 = self.conv4(x4)
+        cb = ops.cat_buffer(x4, [256, 256])                      # [conv4(x4) | upsampled conv3(f3)], written in place
+        up = self.upsample1(self.conv3(f3a), x4.size(), out=cb.slot(1))
+        x4 = self.conv4(x4, out=cb.slot(0))
         assert up.shape[2:] == x4.shape[2:]
-        f2 = self.module2(ops.cat([x4, up]))
+        f2 = self.module2(ops.cat([x4, up], into=cb))
         f2a, f2b = ops.fork(f2)
-        up = self.upsample2(self.conv10(f2a), x3.size())
-        x3 = self.conv11(x3)
+        cb = ops.cat_buffer(x3, [128, 128])
+        up = self.upsample2(self.conv10(f2a), x3.size(), out=cb.slot(1))
+        x3 = self.conv11(x3, out=cb.slot(0))
         assert up.shape[2:] == x3.shape[2:]
-        f1 = self.module3(ops.cat([x3, up]))
+        f1 = self.module3(ops.cat([x3, up], into=cb))
         return f1, f2b, f3b
 
 
@@ -109,13 +111,15 @@ class PANBlock(nn.Module):
 
     def forward(self, f1, f2, f3):
         p1, f1b = ops.fork(f1)
-        p2 = self.conv1(f1b)
+        cb = ops.cat_buffer(f2, [256, f2.shape[1]])
+        p2 = self.conv1(f1b, out=cb.slot(0))
         assert p2.shape[2:] == f2.shape[2:]
-        p2 = self.module1(ops.cat([p2, f2]))
+        p2 = self.module1(ops.cat([p2, f2], into=cb))
         p2a, p2b = ops.fork(p2)
-        p3 = self.conv7(p2a)
+        cb = ops.cat_buffer(f3, [512, f3.shape[1]])
+        p3 = self.conv7(p2a, out=cb.slot(0))
         assert p3.shape[2:] == f3.shape[2:]
-        p3 = self.module2(ops.cat([p3, f3]))
+        p3 = self.module2(ops.cat([p3, f3], into=cb))
         return p1, p2b, p3
 
 
