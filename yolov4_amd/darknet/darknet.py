@@ -63,6 +63,7 @@ class ConvBNAct(nn.Module):
             cfg['running_var'] = n.running_var if (track or not use_batch_stats) else None
             cfg['nbt'] = n.num_batches_tracked if track else None
             gamma, beta = n.weight, n.bias
+            cfg['gamma_param'], cfg['beta_param'] = n.weight, n.bias
         else:
             gamma = beta = None
         w = self.conv.weight

@@ -126,7 +126,7 @@ class BucketedDDP(torch.nn.Module):
             b.flat.zero_()
             for p in b.params:
                 # a zeroed slot may be written in place by the producing kernel (yolov4_amd.ops.ConvBNActFn)
-                p._y4_grad_fresh = p.dim() == 4 and p.grad is not None
+                p._y4_grad_fresh = p.grad is not None
         self.rearm()
 
     def rearm(self):

@@ -266,14 +266,18 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None):
     return z
 
 
-def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act):
+def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None):
+    """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
     L = lib()
     B, C, H, W = y.shape
     dz, lddz = as_nhwc(dz)
     y, ldy = as_nhwc(y)
     dy = empty_nhwc(B, C, H, W, y.device)
-    dgamma = torch.empty(C, device=y.device, dtype=torch.float32)
-    dbeta = torch.empty(C, device=y.device, dtype=torch.float32)
+
+    def slot(t):
+        ok = t is not None and t.dtype == torch.float32 and tuple(t.shape) == (C,) and t.is_contiguous() and t.is_cuda
+        return t if ok else torch.empty(C, device=y.device, dtype=torch.float32)
+    dgamma, dbeta = slot(dgamma_out), slot(dbeta_out)
     nbytes = L.y4_bn_workspace(B * H * W, C)
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
@@ -420,7 +424,18 @@ class ConvBNActFn(torch.autograd.Function):
         k, s, act = cfg['k'], cfg['s'], cfg['act']
         if ctx.mode == 'bn_train':
             x, weight, y, mean, invstd, gamma, beta = ctx.saved_tensors
-            dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act)
+            gp, bp = cfg.get('gamma_param'), cfg.get('beta_param')
+            sink = (gp is not None and bp is not None and getattr(gp, '_y4_grad_fresh', False)
+                    and getattr(bp, '_y4_grad_fresh', False) and gp.grad is not None and bp.grad is not None
+                    and ctx.needs_input_grad[3] and ctx.needs_input_grad[4])
+            dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
+                                               gp.grad if sink else None, bp.grad if sink else None)
+            if sink and dgamma is gp.grad and dbeta is bp.grad:
+                # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
+                gp._y4_grad_fresh = bp._y4_grad_fresh = False
+                gp._y4_grad_ready()
+                bp._y4_grad_ready()
+                dgamma = dbeta = None
             dbias = None
         elif ctx.mode == 'nobn_linear':
             x, weight = ctx.saved_tensors
