@@ -21,6 +21,19 @@ thr = float(torch.quantile(sc[torch.randint(0, sc.numel(), (1000000,), device=de
 torch.cuda.synchronize(); t0 = time.perf_counter()
 det = postprocess(out.clone(), 80, thr, 0.4)
 torch.cuda.synchronize(); dp = time.perf_counter() - t0
-print(json.dumps({'batch': B, 'eval_forward_ms': dt * 1e3, 'img_per_s_forward': B / dt, 'conv_tflops': B / dt * 134.422e9 / 1e12,
+# eval input pipeline: B camera-sized BGR uint8 images already on the device -> [B,3,S,S]
+import numpy as np
+from yolov4_amd.yolo.data.transform import val_batch
+from yolov4_amd.yolo.util.utils import detections_to_coco
+rng = np.random.RandomState(3)
+imgs = [torch.from_numpy(rng.randint(0, 256, (480, 640, 3)).astype(np.uint8)).to(dev) for _ in range(B)]
+val_batch(imgs, S, dev); torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): xb, infos = val_batch(imgs, S, dev)
+torch.cuda.synchronize(); dpre = (time.perf_counter() - t0) / 5
+t0 = time.perf_counter()
+recs = [r for i, d in enumerate(det) for r in detections_to_coco(d, infos[i], i)]
+drec = time.perf_counter() - t0
+print(json.dumps({'preprocess_ms_per_batch': dpre * 1e3, 'coco_records': len(recs), 'coco_records_ms': drec * 1e3,
+                  'batch': B, 'eval_forward_ms': dt * 1e3, 'img_per_s_forward': B / dt, 'conv_tflops': B / dt * 134.422e9 / 1e12,
                   'postprocess_ms': dp * 1e3, 'conf_thre': thr, 'survivors_per_img': sum(0 if d is None else len(d) for d in det) / B,
                   'conv_mode': yolov4_amd.get_conv_mode()}))
