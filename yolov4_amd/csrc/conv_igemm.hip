@@ -384,7 +384,10 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
     }
     const int n0 = nt * BN;
     const int nr = (g.k - r0 + tstep - 1) / tstep, nq = (g.k - q0 + tstep - 1) / tstep;
-    const int lrow = tid >> 3, kc = tid & 7;
+    // rows are dealt so that the two rows one 16-lane ds_write_b64 group covers lie 4 apart (320 B = bank +16):
+    // with adjacent rows (80 B) the groups overlapped on 4 banks -- SQ_LDS_BANK_CONFLICT was 8 % of the wave cycles
+    const int t3 = tid >> 3, kc = tid & 7;
+    const int lrow = (t3 & 0x18) | ((t3 & 1) << 2) | ((t3 >> 1) & 3);
 
     // 32-bit buffer offsets are relative to the first image this tile touches (tensors may exceed 4 GiB)
     const int pix_per_img = classed ? g.cls_h[ph] * g.cls_w[pw] : g.Hd * g.Wd;
@@ -432,7 +435,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_bf16x3(const ConvGeom g) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int slot = tid + 256 * i;
-        const int row = slot >> 2, ch = slot & 3;
+        const int s2 = slot >> 2, ch = slot & 3;
+        const int row = (s2 & ~7) | ((s2 & 1) << 2) | ((s2 >> 1) & 3);     // same dealing for the 8-lane ds_write_b128 groups
         const bool ok = row < BN && (n0 + row) < g.N;
         b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 2u + ch * 16u : OOB;
         b_lds[i] = row < BN ? row * PITCH_B + ch * 16 : -1;
