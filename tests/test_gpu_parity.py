@@ -160,6 +160,27 @@ def test_conv_tensors_beyond_4gib(dev, conv_mode):
     close(dw, parts, 1e-5, 1e-4)
 
 
+@pytest.mark.parametrize('B,ci,co,H', [(3, 64, 64, 211), (2, 32, 64, 300), (2, 64, 128, 270), (2, 64, 32, 301), (2, 64, 96, 270)])
+def test_conv1x1_streaming_kernel(dev, B, ci, co, H):
+    """1x1 layers with K <= 64, N <= 128 and M >= 131072 rows take the persistent streaming kernel (forward, BN-statistics
+    forward and dgrad); M is not a multiple of the 128-row tile here and N = 96 leaves a partly masked column tile."""
+    from yolov4_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + ci + co + H)
+    x = cl(torch.randn((B, ci, H, H), generator=g), dev)
+    w = cl(torch.randn((co, ci, 1, 1), generator=g) * 0.1, dev)
+    dy = cl(torch.randn((B, co, H, H), generator=g), dev)
+    ref = F.conv2d(x.double(), w.double())
+    close(ops.conv_fwd_raw(x, w, 1, 1), ref, 1e-5, 1e-5)
+    close(ops.conv_dgrad_raw(dy, w, (B, ci, H, H), 1, 1), F.conv_transpose2d(dy.double(), w.double()), 1e-5, 1e-5)
+    rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+    nbt = torch.zeros((), dtype=torch.long, device=dev)
+    y, mean, invstd = ops.conv_fwd_bnstats_raw(x, w, 1, 1, rm, rv, nbt, 0.1, 1e-5)
+    close(y, ref, 1e-5, 1e-5)
+    close(mean, ref.mean(dim=(0, 2, 3)), 1e-6, 1e-5, scale=False)
+    close(invstd, (ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5).rsqrt(), 1e-6, 1e-5, scale=False)
+    assert int(nbt) == 1
+
+
 def test_conv_plain_bf16_mode(dev):
     """BASELINE config 5 arithmetic (bf16 MFMA operands, fp32 accumulate): mixed precision, so only a loose
     bound holds against the fp32 reference -- 2^-8 relative per operand -> ~1e-2 of the output range."""
