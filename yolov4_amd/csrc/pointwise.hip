@@ -203,8 +203,30 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
             for (int e = 0; e < 4; ++e) { mu[e] = mean[c0 + e]; is[e] = invstd[c0 + e]; ga[e] = gamma[c0 + e]; be[e] = beta[c0 + e]; }
         }
         f32x4 s = {0, 0, 0, 0}, sx = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int i = 0; i < nrows; ++i) {
+        const int cs = cok ? c0 : 0;                       // loads are unconditional (clamped), results masked:
+        int i = 0;                                         // 8 independent loads in flight per trip
+        for (; i + 3 < nrows; i += 4) {
+            f32x4 v[4], d[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long m = row0 + (long long)(i + u) * rpb + rg;
+                ok[u] = m < M && cok;
+                const long long mm = m < M ? m : M - 1;
+                v[u] = ld4(y + mm * ldy + cs);
+                d[u] = ld4(dz + mm * lddz + cs);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (v[u][e] - mu[e]) * is[e];
+                    const float g = ok[u] ? d[u][e] * y4_act_grad(ga[e] * xh + be[e], act) : 0.f;
+                    s[e] += g;
+                    sx[e] += g * xh;
+                }
+        }
+        for (; i < nrows; ++i) {
             const long long m = row0 + (long long)i * rpb + rg;
             if (m < M && cok) {
                 const f32x4 v = ld4(y + m * ldy + c0);
