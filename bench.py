@@ -145,10 +145,11 @@ def gather_symbol(transposed, M, N, Cs, Cs_valid, k, stride, ld):
     if Cs == 3:
         return 'conv_stem_fwd_bf16x3_kernel' if mode == 'bf16x3' else 'conv_stem_fwd_kernel'
     tr = 'true' if transposed else 'false'
-    if (mode == 'bf16x3' and k == 1 and stride == 1 and Cs in (32, 64) and Cs_valid == Cs and N <= 128
-            and Cs * ((N + 31) // 32 * 32) <= 8192 and M * ld * 4 < 0xfffffff0 and M >= 128 * 1024):
+    if (mode == 'bf16x3' and k == 1 and stride == 1 and Cs in (32, 64, 128) and Cs_valid == Cs and N <= 128
+            and Cs * ((N + 31) // 32 * 32) <= (16384 if Cs == 128 else 8192) and M * ld * 4 < 0xfffffff0 and M >= 128 * 1024):
         nt = (N + 31) // 32
-        return f'conv1x1_stream_bf16x3<{Cs // 16}, {4 if nt >= 3 else nt}>'
+        nt = 4 if nt >= 3 else nt
+        return f'conv1x1_stream_bf16x3<{Cs // 16}, {nt}, {8 if (Cs == 128 and nt == 4) else 4}>'
     split = mode != 'f32'
     kern = 'conv_gather_bf16x3' if split else 'conv_gather_mfma_f32'
     tail = (', 1>' if mode == 'bf16' else ', 3>') if split else None

@@ -160,9 +160,10 @@ def test_conv_tensors_beyond_4gib(dev, conv_mode):
     close(dw, parts, 1e-5, 1e-4)
 
 
-@pytest.mark.parametrize('B,ci,co,H', [(3, 64, 64, 211), (2, 32, 64, 300), (2, 64, 128, 270), (2, 64, 32, 301), (2, 64, 96, 270)])
+@pytest.mark.parametrize('B,ci,co,H', [(3, 64, 64, 211), (2, 32, 64, 300), (2, 64, 128, 270), (2, 64, 32, 301), (2, 64, 96, 270),
+                                       (2, 128, 128, 270), (2, 128, 64, 263), (2, 128, 32, 257)])
 def test_conv1x1_streaming_kernel(dev, B, ci, co, H):
-    """1x1 layers with K <= 64, N <= 128 and M >= 131072 rows take the persistent streaming kernel (forward, BN-statistics
+    """1x1 layers with K <= 128, N <= 128 and M >= 131072 rows take the persistent streaming kernel (forward, BN-statistics
     forward and dgrad); M is not a multiple of the 128-row tile here and N = 96 leaves a partly masked column tile."""
     from yolov4_amd import ops
     g = torch.Generator().manual_seed(B * 1000 + ci + co + H)

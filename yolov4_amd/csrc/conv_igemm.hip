@@ -738,8 +738,11 @@ int g_conv_mode = 1;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x
 // memory straight into the MFMA A-operand layout (lane = pixel, 8 consecutive channels = 32 contiguous bytes),
 // splits them in registers and never meets a barrier; the next tile's loads fly under this tile's MFMAs/stores.
 // Used for forward (filter planes [N][K]) and for 1x1 dgrad (planes of the transposed filter).
-template <int KS, int NT>
-__global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g) {
+// NW waves per block: 4, or 8 where the filter planes allow one block per CU only (K = N = 128: 104 KB) so that every
+// SIMD still holds two waves
+template <int KS, int NT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_bf16x3(const ConvGeom g) {
+    constexpr int NTHR = NW * 64, TROWS = NW * 32;
     constexpr int K = KS * 16;
     constexpr int PITCH = K * 2 + 16;                    // LDS row pitch: conflict-free ds_read_b128 for K = 32/64/128
     constexpr int N32 = NT * 32;
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
     {
         constexpr int CPR = K / 8;                       // 16-B chunks per filter row
         const unsigned char* wp = reinterpret_cast<const unsigned char*>(g.wt_planes);
-        for (int i = tid; i < 3 * N32 * CPR; i += 256) {
+        for (int i = tid; i < 3 * N32 * CPR; i += NTHR) {
             const int pl = i / (N32 * CPR);
             const int rem = i - pl * (N32 * CPR);
             const int row = rem / CPR, ch = rem - row * CPR;
@@ -763,14 +766,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
     const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, (unsigned)g.src_total_bytes);   // < 4 GiB (host)
     const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
     const int mtiles = g.mtiles;
-    f32x4 ra0[KS][2], ra1[KS][2];
-    auto load = [&](f32x4 (&ra)[KS][2], int tile) {
-        const int m = tile * 128 + wave * 32 + fr;
+    // KH k-steps per register set: K <= 64 keeps a whole tile per set (two tiles in flight); K = 128 keeps half a tile
+    // per set, the two halves of one tile alternating (the other half's loads fly under this half's MFMAs)
+    constexpr int KH = KS == 8 ? 4 : KS;
+    f32x4 ra0[KH][2], ra1[KH][2];
+    auto load = [&](f32x4 (&ra)[KH][2], int tile, int ks0) {
+        const int m = tile * TROWS + wave * 32 + fr;
         const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 32u : 0xffffffffu;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            ra[ks][0] = y4_buf_load4(src_rsrc, off, (unsigned)ks * 64u);
-            ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)ks * 64u + 16u);
+        for (int ks = 0; ks < KH; ++ks) {
+            ra[ks][0] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 64u);
+            ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 64u + 16u);
         }
     };
     float cs[NT], css[NT];
@@ -783,14 +789,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
         sh[j] = (g.shift && n < g.N) ? g.shift[n] : 0.0f;
     }
     const unsigned char* b_frag = smem_b + fr * PITCH + fh * 16;
-    auto compute = [&](f32x4 (&ra)[KS][2], int tile) {
-        f32x16 acc[NT];
+    f32x16 acc[NT];
+    auto zero_acc = [&]() {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    };
+    auto mma = [&](f32x4 (&ra)[KH][2], int ks0) {
+        // the filter fragments are loop-invariant; at K = 128 keeping them all in registers (up to 384) spills, so the
+        // compiler is told the LDS may have changed and re-reads them per tile (ds_read_b128 is cheap beside 6 MFMAs)
+        if constexpr (KS == 8) asm volatile("" ::: "memory");
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int ks = 0; ks < KH; ++ks) {
             u32x2 a1, a2, a3, b1, b2, b3;
             split3x4(ra[ks][0], a1, a2, a3);
             split3x4(ra[ks][1], b1, b2, b3);
@@ -802,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
                 bf16x8 fb[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    fb[pl] = *reinterpret_cast<const bf16x8*>(b_frag + (pl * N32 + j * 32) * PITCH + ks * 32);
+                    fb[pl] = *reinterpret_cast<const bf16x8*>(b_frag + (pl * N32 + j * 32) * PITCH + (ks0 + ks) * 32);
                 f32x16 c = acc[j];
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[0], c, 0, 0, 0);
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[1], c, 0, 0, 0);
@@ -813,7 +824,9 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
                 acc[j] = c;
             }
         }
-        const int mbase = tile * 128 + wave * 32 + 4 * fh;
+    };
+    auto epilogue = [&](int tile) {
+        const int mbase = tile * TROWS + wave * 32 + 4 * fh;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + fr;
@@ -833,20 +846,33 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
         }
     };
     int tile = blockIdx.x;
-    if (tile < mtiles) load(ra0, tile);
-    while (tile < mtiles) {
-        const int t1 = tile + gridDim.x;
-        if (t1 < mtiles) load(ra1, t1);
-        compute(ra0, tile);
-        if (t1 >= mtiles) break;
-        const int t2 = t1 + gridDim.x;
-        if (t2 < mtiles) load(ra0, t2);
-        compute(ra1, t1);
-        tile = t2;
+    if (tile < mtiles) load(ra0, tile, 0);
+    if constexpr (KS == 8) {
+        while (tile < mtiles) {
+            load(ra1, tile, KH);
+            zero_acc();
+            mma(ra0, 0);
+            const int tn = tile + gridDim.x;
+            if (tn < mtiles) load(ra0, tn, 0);
+            mma(ra1, KH);
+            epilogue(tile);
+            tile = tn;
+        }
+    } else {
+        while (tile < mtiles) {
+            const int t1 = tile + gridDim.x;
+            if (t1 < mtiles) load(ra1, t1, 0);
+            zero_acc(); mma(ra0, 0); epilogue(tile);
+            if (t1 >= mtiles) break;
+            const int t2 = t1 + gridDim.x;
+            if (t2 < mtiles) load(ra0, t2, 0);
+            zero_acc(); mma(ra1, 0); epilogue(t1);
+            tile = t2;
+        }
     }
     if (g.stats) {                                        // one partial row per block: [gridDim][2][N]
         __syncthreads();                                  // every wave is done with the filter planes
-        float* red = reinterpret_cast<float*>(smem_b);    // [4][N32][2]
+        float* red = reinterpret_cast<float*>(smem_b);    // [NW][N32][2]
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             float a = cs[j], b = css[j];
@@ -855,10 +881,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
             if (fh == 0) { red[(wave * N32 + j * 32 + fr) * 2] = a; red[(wave * N32 + j * 32 + fr) * 2 + 1] = b; }
         }
         __syncthreads();
-        for (int c = tid; c < N32; c += 256) {
+        for (int c = tid; c < N32; c += NTHR) {
             float a = 0.f, b = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { a += red[(w * N32 + c) * 2]; b += red[(w * N32 + c) * 2 + 1]; }
+            for (int w = 0; w < NW; ++w) { a += red[(w * N32 + c) * 2]; b += red[(w * N32 + c) * 2 + 1]; }
             if (c < g.N) {
                 g.stats[((long long)blockIdx.x * 2 + 0) * g.N + c] = a;
                 g.stats[((long long)blockIdx.x * 2 + 1) * g.N + c] = b;
@@ -867,35 +893,36 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_bf16x3(const ConvGeom g
     }
 }
 
-template <int KS, int NT>
+template <int KS, int NT, int NW = 4>
 int launch_stream1x1(const ConvGeom& g0, hipStream_t st, int* nparts) {
     ConvGeom g = g0;
-    g.mtiles = (g.M + 127) / 128;
+    g.mtiles = (g.M + NW * 32 - 1) / (NW * 32);
     g.ntiles = 1;
     g.src_total_bytes = (unsigned long long)g.M * (unsigned long long)g.lds_ * 4ull;
     const size_t smem = (size_t)3 * NT * 32 * (KS * 32 + 16);
-    auto kern = conv1x1_stream_bf16x3<KS, NT>;
+    auto kern = conv1x1_stream_bf16x3<KS, NT, NW>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
-    const int grid = g.mtiles < 512 ? g.mtiles : 512;     // 2 resident blocks per CU
+    const int resident = smem > 80 * 1024 ? 256 : 512;    // blocks per CU by LDS: 1 (K = N = 128) or 2
+    const int grid = g.mtiles < resident ? g.mtiles : resident;
     if (nparts) *nparts = grid;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
 
-// eligibility: bf16x3 arithmetic, 1x1 stride 1, K in {32,64}, N <= 128, filter planes <= 52 KB of LDS,
+// eligibility: bf16x3 arithmetic, 1x1 stride 1, K in {32,64,128}, N <= 128, filter planes <= 52 KB of LDS,
 // 32-bit addressable source, every source channel valid, and enough rows to be worth a persistent launch
 static bool stream1x1_ok(const ConvGeom& g) {
     if (g_conv_mode != 1 || g.k != 1 || g.stride != 1 || !g.wt_planes) return false;
-    if (g.Cs != 32 && g.Cs != 64) return false;       // K = 128 needs > 256 VGPRs with two register stages
+    if (g.Cs != 32 && g.Cs != 64 && g.Cs != 128) return false;
     if (g.Cs_valid != g.Cs || g.N > 128) return false;
     const int n32 = (g.N + 31) / 32 * 32;
-    if (g.Cs * n32 > 8192) return false;
+    if (g.Cs * n32 > (g.Cs == 128 ? 16384 : 8192)) return false;     // filter planes: <= 52 KB (2 blocks/CU) or 104 KB at K = 128
     if ((unsigned long long)g.M * (unsigned long long)g.lds_ * 4ull >= 0xfffffff0ull) return false;
     return g.M >= 128 * 1024;
 }
@@ -909,6 +936,9 @@ static int dispatch_stream1x1(const ConvGeom& g, hipStream_t st, int* nparts) {
         case 41: return launch_stream1x1<4, 1>(g, st, nparts);
         case 42: return launch_stream1x1<4, 2>(g, st, nparts);
         case 43: case 44: return launch_stream1x1<4, 4>(g, st, nparts);
+        case 81: return launch_stream1x1<8, 1>(g, st, nparts);
+        case 82: return launch_stream1x1<8, 2>(g, st, nparts);
+        case 83: case 84: return launch_stream1x1<8, 4, 8>(g, st, nparts);
         default: return Y4_ERR_SHAPE;
     }
 }
