@@ -182,6 +182,22 @@ def test_conv1x1_streaming_kernel(dev, B, ci, co, H):
     assert int(nbt) == 1
 
 
+def test_conv_non_finite_inputs_stay_non_finite(dev, conv_mode):
+    """A NaN or Inf activation must not be laundered into a finite number by the operand split (bf16x3: x - trunc(x)
+    of an Inf is NaN, so an Inf input surfaces as NaN where the fp32 chain gives +-Inf -- both are non-finite)."""
+    from yolov4_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((1, 64, 12, 12), generator=g)
+    x[0, 3, 5, 5] = float('nan')
+    x[0, 7, 2, 9] = float('inf')
+    w = torch.randn((32, 64, 3, 3), generator=g) * 0.1
+    y = ops.conv_fwd_raw(cl(x, dev), cl(w, dev), 3, 1).cpu()
+    ref = F.conv2d(x, w, padding=1)
+    assert torch.equal(torch.isfinite(y), torch.isfinite(ref))
+    assert torch.isnan(y[0, :, 4:7, 4:7]).all()
+    close(torch.nan_to_num(y, 0.0, 0.0, 0.0), torch.nan_to_num(ref, 0.0, 0.0, 0.0), 1e-5, 1e-5)
+
+
 def test_conv_plain_bf16_mode(dev):
     """BASELINE config 5 arithmetic (bf16 MFMA operands, fp32 accumulate): mixed precision, so only a loose
     bound holds against the fp32 reference -- 2^-8 relative per operand -> ~1e-2 of the output range."""
