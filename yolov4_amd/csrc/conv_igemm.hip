@@ -1835,10 +1835,8 @@ size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
 
 static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx, int lddx,
                            int B, int H, int W, int Cin, int Cout, int k, int stride,
-                           const float* addend, int ld_addend,
                            void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
-    if (addend && ld_addend < Cin) return Y4_ERR_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
     const int Cout_pad = (Cout + 31) / 32 * 32;
@@ -1858,9 +1856,9 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     Y4_CHECK_LAUNCH();
     const int pad = (k - 1) / 2;
     ConvGeom g{};
-    g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = addend;
+    g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = nullptr;
     g.wt_planes = static_cast<const unsigned short*>(workspace);
-    g.lds_ = lddy; g.ldd = lddx; g.ldr = ld_addend;
+    g.lds_ = lddy; g.ldd = lddx; g.ldr = 0;
     g.B = B;
     g.Hs = (H + 2 * pad - k) / stride + 1;
     g.Ws = (W + 2 * pad - k) / stride + 1;
@@ -1875,8 +1873,7 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes, void* stream) {
-    return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, nullptr, 0, workspace, workspace_bytes,
-                           stream);
+    return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, stream);
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
