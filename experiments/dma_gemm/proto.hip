@@ -1,0 +1,151 @@
+// PROTOTYPE (not part of libyolov4_amd.so): what does the conv arithmetic reach when both operands arrive as bf16
+// planes by LDS-DMA instead of being split in registers?  C[M][N] (fp32) = sum_k A[m][k] * B[n][k], both operands given
+// as three exact bf16 planes [3][rows][K] (x = p1 + p2 + p3), six MFMAs per product as in conv_gather_bf16x3.
+// Structure: one 8-wave block per CU, tile 256 x 256, BK = 16, three LDS stages of 48 KB, global_load_lds 16 B per lane
+// into a lane-linear image whose 16-B chunks are XOR-swizzled on the SOURCE address, two K-tiles of DMA in flight across
+// raw s_barriers with a counted vmcnt, 48 MFMAs per wave and K-tile, one barrier per K-tile.
+// (First variant, 256 x 128 x 32 with two stages and vmcnt(0) + __syncthreads(): 88-131 TFLOP/s, i.e. no better than the
+// register-staged product kernel -- one tile of DMA in flight does not cover the L2 latency.)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int BM = 256, BN = 256, BK = 16, NSTAGE = 3;
+constexpr int ROWB = BK * 2;                                  // 32 B per row per plane
+constexpr int A_BYTES = 3 * BM * ROWB, B_BYTES = 3 * BN * ROWB, STAGE = A_BYTES + B_BYTES;   // 72 KB
+constexpr int NDMA = STAGE / (512 * 16);                      // 6 wave-instructions per wave and K-tile
+
+__global__ void split_planes_kernel(const float* __restrict__ x, unsigned short* __restrict__ planes, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        const unsigned h1 = __float_as_uint(v);
+        const float r1 = v - __uint_as_float(h1 & 0xffff0000u);
+        const unsigned h2 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(h2 & 0xffff0000u);
+        planes[i] = (unsigned short)(h1 >> 16);
+        planes[n + i] = (unsigned short)(h2 >> 16);
+        planes[2 * n + i] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+}
+
+// one stage: [A plane 0..2][256 rows][32 B] | [B plane 0..2][256 rows][32 B]; 16-B chunk c of row r sits at slot c ^ ((r >> 3) & 1)
+__global__ __launch_bounds__(512, 1) void gemm_planes_dma_kernel(const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp,
+                                                                 float* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;                  // 2 x 4 waves, 128 x 64 each
+    const int ntn = N / BN;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const long long m0 = (long long)mt * BM, n0 = (long long)nt * BN;
+    const long long a_plane = (long long)M * K, b_plane = (long long)N * K;    // elements per plane
+    const int KT = K / BK;
+
+    // DMA slots of this lane: instruction i of wave w covers stage bytes [(w * NDMA + i) * 1024, +1024)
+    const unsigned short* src[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int byte = (wave * NDMA + i) * 1024 + lane * 16;
+        const bool isA = byte < A_BYTES;
+        const int b2 = isA ? byte : byte - A_BYTES;
+        const int rows = isA ? BM : BN;
+        const int pl = b2 / (rows * ROWB);
+        const int rem = b2 - pl * rows * ROWB;
+        const int row = rem / ROWB, slot = (rem % ROWB) / 16;
+        const int chunk = slot ^ ((row >> 3) & 1);
+        src[i] = isA ? Ap + pl * a_plane + (m0 + row) * K + chunk * 8
+                     : Bp + pl * b_plane + (n0 + row) * K + chunk * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i)
+            __builtin_amdgcn_global_load_lds(src[i] + kt * BK,
+                                             reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                                 reinterpret_cast<uintptr_t>(smem + buf * STAGE + (wave * NDMA + i) * 1024)),
+                                             16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+    // three stages, two K-tiles of DMA in flight: wait only for the OLDER one (counted vmcnt), raw barrier (no vmcnt(0)),
+    // then refill the stage everybody has just finished reading, then compute
+    issue(0, 0);
+    if (KT > 1) issue(1, 1);
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < KT) issue(kt + 2, (kt + 2) % NSTAGE);
+        const unsigned char* As = smem + (kt % NSTAGE) * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+        bf16x8 fa[4][3], fb[2][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 128 + i * 32 + fr;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fa[i][pl] = *reinterpret_cast<const bf16x8*>(As + (pl * BM + row) * ROWB + ((fh ^ ((row >> 3) & 1)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = wn * 64 + j * 32 + fr;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                fb[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + row) * ROWB + ((fh ^ ((row >> 3) & 1)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x16 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][2], fb[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long n = n0 + wn * 64 + j * 32 + fr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long m = m0 + wm * 128 + i * 32 + 4 * fh + (e & 3) + 8 * (e >> 2);
+                if (m < M) C[m * N + n] = acc[i][j][e];
+            }
+        }
+}
+}  // namespace
+
+extern "C" {
+int proto_split(const float* x, unsigned short* planes, long long n, void* stream) {
+    hipLaunchKernelGGL(split_planes_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, planes, n);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+// requires M % 256 == 0, N % 256 == 0, K % 16 == 0 (prototype: no tails)
+int proto_gemm(const unsigned short* Ap, const unsigned short* Bp, float* C, int M, int N, int K, void* stream) {
+    if (M % BM || N % BN || K % BK) return 2;
+    static bool done = false;
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_planes_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                NSTAGE * STAGE) != hipSuccess) return 3;
+        done = true;
+    }
+    hipLaunchKernelGGL(gemm_planes_dma_kernel, dim3((M / BM) * (N / BN)), dim3(512), NSTAGE * STAGE, (hipStream_t)stream, Ap, Bp, C, M, N, K);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+}
