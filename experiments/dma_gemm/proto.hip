@@ -39,7 +39,10 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_dma_kernel(const unsigned 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;                  // 2 x 4 waves, 128 x 64 each
     const int ntn = N / BN;
-    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    // XCD-aware order: blocks b, b+8, b+16, ... share an XCD (and its L2); give each XCD a contiguous run of tiles
+    const int nblk = gridDim.x, xcd = blockIdx.x & 7, q = nblk >> 3, r = nblk & 7;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int mt = bid / ntn, nt = bid - mt * ntn;
     const long long m0 = (long long)mt * BM, n0 = (long long)nt * BN;
     const long long a_plane = (long long)M * K, b_plane = (long long)N * K;    // elements per plane
     const int KT = K / BK;
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_dma_kernel(const unsigned 
             for (int pl = 0; pl < 3; ++pl)
                 fb[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + (pl * BN + row) * ROWB + ((fh ^ ((row >> 3) & 1)) << 4));
         }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_dma_kernel(const unsigned 
                 c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], c, 0, 0, 0);
                 acc[i][j] = c;
             }
+        __builtin_amdgcn_s_setprio(0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -129,9 +134,37 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_dma_kernel(const unsigned 
             }
         }
 }
+// Sustained matrix-pipe rate with nothing else going on: every wave issues 32x32x16 bf16 MFMAs on register operands
+// (random data, 4 independent accumulators), 8 waves per CU.  The ceiling the power envelope leaves.
+__global__ __launch_bounds__(512, 1) void mfma_peak_kernel(const unsigned* __restrict__ seed, float* __restrict__ out, int iters) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    u32x4 a = {seed[tid & 1023], seed[(tid + 1) & 1023], seed[(tid + 2) & 1023], seed[(tid + 3) & 1023]};
+    u32x4 b = {seed[(tid + 4) & 1023], seed[(tid + 5) & 1023], seed[(tid + 6) & 1023], seed[(tid + 7) & 1023]};
+    const bf16x8 fa = __builtin_bit_cast(bf16x8, a), fb = __builtin_bit_cast(bf16x8, b);
+    f32x16 c0, c1, c2, c3;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { c0[e] = 0.f; c1[e] = 0.f; c2[e] = 0.f; c3[e] = 0.f; }
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fa, c1, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fa, c2, 0, 0, 0);
+            c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb, fb, c3, 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s += c0[e] + c1[e] + c2[e] + c3[e];
+    out[tid] = s;
+}
 }  // namespace
 
 extern "C" {
+int proto_mfma_peak(const unsigned* seed, float* out, int iters, void* stream) {
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(256), dim3(512), 0, (hipStream_t)stream, seed, out, iters);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 int proto_split(const float* x, unsigned short* planes, long long n, void* stream) {
     hipLaunchKernelGGL(split_planes_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, planes, n);
     return hipGetLastError() == hipSuccess ? 0 : 1;

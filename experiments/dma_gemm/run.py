@@ -40,6 +40,17 @@ print('check: max err / range =', err)
 assert err < 1e-6
 
 from yolov4_amd import ops
+# sustained MFMA-only rate (random bf16 operands in registers, 8 waves per CU, ~50 ms)
+L.proto_mfma_peak.argtypes = [P, P, I, P]
+seed = (torch.randn(1024, device=dev) * 1.0).view(torch.int32)
+out = torch.empty(256 * 512, device=dev)
+for iters in (2000, 20000, 20000):
+    L.proto_mfma_peak(seed.data_ptr(), out.data_ptr(), iters, st()); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); L.proto_mfma_peak(seed.data_ptr(), out.data_ptr(), iters, st()); e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1)
+    fl = 256 * 8 * iters * 16 * 2.0 * 32 * 32 * 16
+    print(f'MFMA-only loop: {iters} iters {t:8.2f} ms -> {fl / t / 1e9:7.0f} TFLOP/s bf16 sustained', flush=True)
 # full-machine shapes first (256 or 512 blocks of 256 x 256: no tile quantisation), then the layer shapes
 for (M, K, N) in [(65536, 512, 256), (65536, 4608, 256), (131072, 4608, 256), (65536, 2304, 512)]:
     A = torch.randn((M, K), device=dev); B = torch.randn((N, K), device=dev) * 0.05
