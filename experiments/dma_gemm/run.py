@@ -12,7 +12,8 @@ if not os.path.isfile(so):
                            os.path.join(HERE, 'proto.hip'), '-o', so])
 L = ctypes.CDLL(so)
 P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
-L.proto_split.argtypes = [P, P, LL, P]; L.proto_gemm.argtypes = [P, P, P, I, I, I, P]
+L.proto_split.argtypes = [P, P, LL, P]; L.proto_gemm.argtypes = [P, P, P, I, I, I, P]; L.proto_gemm2.argtypes = [P, P, P, I, I, I, P]
+VARIANT = int(os.environ.get('PROTO_VARIANT', '1'))
 dev = torch.device('cuda:0')
 st = lambda: torch.cuda.current_stream().cuda_stream
 
@@ -25,7 +26,7 @@ def planes(x):
 
 def gemm(Ap, Bp, M, N, K):
     C = torch.empty((M, N), dtype=torch.float32, device=dev)
-    rc = L.proto_gemm(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), M, N, K, st())
+    rc = (L.proto_gemm if VARIANT == 1 else L.proto_gemm2)(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), M, N, K, st())
     assert rc == 0, rc
     return C
 
