@@ -8,6 +8,7 @@
 // register-staged product kernel -- one tile of DMA in flight does not cover the L2 latency.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,7 +35,7 @@ __global__ void split_planes_kernel(const float* __restrict__ x, unsigned short*
 
 // one stage: [A plane 0..2][256 rows][32 B] | [B plane 0..2][256 rows][32 B]; 16-B chunk c of row r sits at slot c ^ ((r >> 3) & 1)
 __global__ __launch_bounds__(512, 1) void gemm_planes_dma_kernel(const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp,
-                                                                 float* __restrict__ C, int M, int N, int K) {
+                                                                 float* __restrict__ C, int M, int N, int K, int mode) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;                  // 2 x 4 waves, 128 x 64 each
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(512, 1) void gemm_planes_dma_kernel(const unsigned 
         if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < KT) issue(kt + 2, (kt + 2) % NSTAGE);
-        const unsigned char* As = smem + (kt % NSTAGE) * STAGE;
+        if (kt + 2 < KT && mode != 1) issue(kt + 2, (kt + 2) % NSTAGE);
+        const unsigned char* As = smem + ((mode == 2 ? 0 : kt) % NSTAGE) * STAGE;
         const unsigned char* Bs = As + A_BYTES;
         bf16x8 fa[4][3], fb[2][3];
 #pragma unroll
@@ -282,6 +283,8 @@ int proto_split(const float* x, unsigned short* planes, long long n, void* strea
 }
 // requires M % 256 == 0, N % 256 == 0, K % 16 == 0 (prototype: no tails)
 int proto_gemm(const unsigned short* Ap, const unsigned short* Bp, float* C, int M, int N, int K, void* stream) {
+    const char* e = getenv("PROTO_MODE");
+    const int mode = e ? atoi(e) : 0;
     if (M % BM || N % BN || K % BK) return 2;
     static bool done = false;
     if (!done) {
@@ -289,7 +292,7 @@ int proto_gemm(const unsigned short* Ap, const unsigned short* Bp, float* C, int
                                 NSTAGE * STAGE) != hipSuccess) return 3;
         done = true;
     }
-    hipLaunchKernelGGL(gemm_planes_dma_kernel, dim3((M / BM) * (N / BN)), dim3(512), NSTAGE * STAGE, (hipStream_t)stream, Ap, Bp, C, M, N, K);
+    hipLaunchKernelGGL(gemm_planes_dma_kernel, dim3((M / BM) * (N / BN)), dim3(512), NSTAGE * STAGE, (hipStream_t)stream, Ap, Bp, C, M, N, K, mode);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 }
