@@ -12,7 +12,7 @@ if not os.path.isfile(so):
                            os.path.join(HERE, 'proto.hip'), '-o', so])
 L = ctypes.CDLL(so)
 P, I, LL = ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong
-L.proto_split.argtypes = [P, P, LL, P]; L.proto_gemm.argtypes = [P, P, P, I, I, I, P]; L.proto_gemm2.argtypes = [P, P, P, I, I, I, P]
+L.proto_split.argtypes = [P, P, LL, P]; L.proto_gemm.argtypes = [P, P, P, I, I, I, P]; L.proto_gemm2.argtypes = [P, P, P, I, I, I, P]; L.proto_gemm3.argtypes = [P, P, P, I, I, I, P]
 VARIANT = int(os.environ.get('PROTO_VARIANT', '1'))
 dev = torch.device('cuda:0')
 st = lambda: torch.cuda.current_stream().cuda_stream
@@ -24,9 +24,19 @@ def planes(x):
     return p
 
 
+_RAW = {}
+
+
+def planes_or_raw(x):
+    if VARIANT == 3:
+        return x
+    return planes(x)
+
+
 def gemm(Ap, Bp, M, N, K):
     C = torch.empty((M, N), dtype=torch.float32, device=dev)
-    rc = (L.proto_gemm if VARIANT == 1 else L.proto_gemm2)(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), M, N, K, st())
+    fn = {1: L.proto_gemm, 2: L.proto_gemm2, 3: L.proto_gemm3}[VARIANT]
+    rc = fn(Ap.data_ptr(), Bp.data_ptr(), C.data_ptr(), M, N, K, st())
     assert rc == 0, rc
     return C
 
@@ -34,7 +44,7 @@ def gemm(Ap, Bp, M, N, K):
 g = torch.Generator().manual_seed(0)
 M, N, K = 512, 256, 160 // 32 * 32
 A = torch.randn((M, K), generator=g).to(dev); B = (torch.randn((N, K), generator=g) * 0.1).to(dev)
-C = gemm(planes(A), planes(B), M, N, K)
+C = gemm(planes_or_raw(A), planes(B), M, N, K)
 ref = A.double() @ B.double().t()
 err = float((C.double() - ref).abs().max() / ref.abs().max())
 print('check: max err / range =', err)
@@ -55,7 +65,7 @@ for iters in (2000, 20000, 20000):
 # full-machine shapes first (256 or 512 blocks of 256 x 256: no tile quantisation), then the layer shapes
 for (M, K, N) in [(65536, 512, 256), (65536, 4608, 256), (131072, 4608, 256), (65536, 2304, 512)]:
     A = torch.randn((M, K), device=dev); B = torch.randn((N, K), device=dev) * 0.05
-    Ap, Bp = planes(A), planes(B)
+    Ap, Bp = planes_or_raw(A), planes(B)
     gemm(Ap, Bp, M, N, K); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -68,7 +78,7 @@ for (M, K, N) in [(65536, 512, 256), (65536, 4608, 256), (131072, 4608, 256), (6
 for (H, K, N) in [(38, 512, 256), (19, 1024, 512), (38, 256, 256), (19, 512, 512), (19, 4608, 1024)]:
     M = 64 * H * H // 256 * 256
     A = torch.randn((M, K), device=dev); B = torch.randn((N, K), device=dev) * 0.05
-    Ap, Bp = planes(A), planes(B)
+    Ap, Bp = planes_or_raw(A), planes(B)
     gemm(Ap, Bp, M, N, K); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
