@@ -2,7 +2,8 @@
 # -*- coding: utf-8 -*-
 """Headline benchmark (BASELINE.json): images/sec of one YOLOv4 training step
 (forward + YOLOLoss + backward, no optimizer) at 608x608, batch 64 per GPU,
-synthetic inputs per SURVEY.md §8(d) config 3, exact-fp32 MFMA path.
+synthetic inputs per SURVEY.md §8(d) config 3, fp32-grade conv arithmetic (bf16x3 by default, --conv-mode f32 for
+the fp32 MFMA).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -10,8 +11,8 @@ synthetic inputs per SURVEY.md §8(d) config 3, exact-fp32 MFMA path.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live: every launch of the
 convolution kernels inside the timed steps is bracketed by HIP events on the
-launch stream; achieved = algorithmic conv FLOPs of those launches / their summed
-durations, for the kernel family with the largest total time.  `cpu_baseline` is
+launch stream and attributed to the kernel symbol the dispatcher picks; achieved = algorithmic conv FLOPs of the
+launches of the ONE symbol with the largest total time / their summed durations (`per_symbol` lists all of them).  `cpu_baseline` is
 the oracle (torch CPU fp32 restatement of the reference) running the same step
 on the host cores at a bounded batch.
 """
@@ -25,6 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+# the pool's host driver only supports dmabuf IPC (RCCL / cross-process tensor sharing); already exported there
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import numpy as np
 import torch
