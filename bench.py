@@ -185,6 +185,17 @@ def pmc_traffic_symbol(sym):
     return None
 
 
+def pmc_mfma_util(sym):
+    """Cycle-based matrix-pipe utilisation of one kernel symbol from the recorded rocprofv3 --pmc pass of this command
+    (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x elapsed cycles), profiles/r01_pmc_mfma_util_per_kernel_v10.json)."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_mfma_util_per_kernel_v10.json')
+    if os.path.isfile(path):
+        for k, v in json.load(open(path)).items():
+            if sym in k:
+                return v['mfma_util']
+    return None
+
+
 def pmc_traffic(kind):
     """HBM-side bytes per launch of the kernel family (largest tile variant), from the separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/, corrected as
@@ -360,6 +371,7 @@ def main():
             out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': peak,
                                'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / peak,
                                'traffic': pmc_traffic_symbol(dsym),
+                               'mfma_util_pmc': pmc_mfma_util(dsym),
                                'kernel': dsym,
                                'peak_note': {'bf16x3': 'dense bf16 MFMA peak 2500 / 6 MFMAs per fp32-exact product',
                                              'bf16': 'dense bf16 MFMA peak', 'f32': 'dense fp32 MFMA peak'}[args.conv_mode],
