@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_dma2_kernel(const unsigned
 namespace vc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int BM = 256, BN = 256, BK = 16, NSTAGE = 3;
+constexpr int BM = 256, BN = 256, BK = 16, NSTAGE = 4;
 constexpr int A_BYTES = BM * BK * 4, B_BYTES = 3 * BN * BK * 2, STAGE = A_BYTES + B_BYTES;   // 16 + 24 = 40 KB
 constexpr int NDMA = STAGE / (512 * 16);                                                     // 5
 __device__ __forceinline__ unsigned pack_hi16(unsigned hi, unsigned lo) { return __builtin_amdgcn_perm(hi, lo, 0x07060302u); }
@@ -310,11 +310,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32a_dma_kernel(const float* __re
     const int fr = lane & 31, fh = lane >> 5;
     issue(0, 0);
     if (KT > 1) issue(1, 1);
+    if (KT > 2) issue(2, 2);
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // two younger tiles may still be in flight
+        else if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (kt + 2 < KT && mode != 1) issue(kt + 2, (kt + 2) % NSTAGE);
+        if (kt + 3 < KT && mode != 1) issue(kt + 3, (kt + 3) % NSTAGE);
         const unsigned char* As = smem + (kt % NSTAGE) * STAGE;
         const unsigned char* Bs = As + A_BYTES;
         f32x4 ra[4][2];
