@@ -249,6 +249,25 @@ int y4_nms_f32(const float* boxes, const float* scores /* may be NULL */, long l
                int limit, int* keep_idx /* [R] */, int* n_keep /* [1] */,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------- stand-alone forms of fused pieces
+ * bboxes_iou (yolo/model/yololoss.py:16-91): pairwise IoU [Na,4] x [Nb,4] -> iou[Na*Nb] row-major; xyxy != 0:
+ * corner boxes, else (xc, yc, w, h).  Same fp32 operation sequence as the reference (bit-exact on the CPU fixtures);
+ * the target-assignment / ignore-mask kernels carry their own inlined copies. */
+int y4_bboxes_iou_f32(const float* boxes_a, long long Na, const float* boxes_b, long long Nb, int xyxy, float* iou,
+                      void* stream);
+/* Mish.forward (darknet/darknet.py:14-20) and the other activations of ConvBNAct as a flat elementwise sweep over a
+ * dense tensor of n floats (act = Y4_ACT_*); backward: dx = dy * act'(x). */
+int y4_act_fwd_f32(const float* x, float* y, long long n, int act, void* stream);
+int y4_act_bwd_f32(const float* x, const float* dy, float* dx, long long n, int act, void* stream);
+/* Upsample.forward (yolo/model/yolov4.py:82-90) for any target size, NHWC with pitches.  integer_factor = 0: the
+ * train branch, F.interpolate(size=(Ho,Wo), mode='nearest'): src = min(floor(dst * (float)in/out), in-1);
+ * integer_factor = 1: the eval branch (view/expand by Ho/H, Wo/W; Y4_ERR_SHAPE unless Ho % H == Wo % W == 0).
+ * Backward sums each source pixel's destination block in a fixed order. */
+int y4_upsample_nearest_fwd_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int Ho, int Wo, int C,
+                                int integer_factor, void* stream);
+int y4_upsample_nearest_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int B, int H, int W, int Ho, int Wo, int C,
+                                int integer_factor, void* stream);
+
 /* ---------------------------------------------------------------- optimizer ("next" row 1)
  * Fused Adam step over one dense parameter block; replaces torch.optim.Adam as the reference builds
  * it (yolo/optim/optimizers/adam.py:14-15: betas (0.9, 0.999), eps 1e-8; both param groups of
@@ -256,6 +275,18 @@ int y4_nms_f32(const float* boxes, const float* scores /* may be NULL */, long l
 int y4_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n,
                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      float grad_scale, void* stream);
+/* Multi-tensor form: ONE launch steps every parameter of the model.  chunks_dev is a device table of 48-byte
+ * records {float* p; const float* g; float* m; float* v; int64 n; int64 hyper_row} (Adam: m = exp_avg,
+ * v = exp_avg_sq; SGD: m = momentum_buffer, v unused); a chunk is a contiguous run of one tensor (the host cuts
+ * tensors into runs of 64 Ki elements).  hyper_host holds nhyper (<= 16) rows of 4 floats, one per distinct
+ * (param group, step count): Adam {lr/bc1, 1/sqrt(bc2), weight_decay, 0} as y4_adam_hyper_f32 computes them in
+ * double (the same values y4_adam_step_f32 uses, so both forms are bit-identical); SGD {lr, momentum,
+ * weight_decay, first_step(0/1)} with torch.optim.SGD semantics (sgd.py:14-15: dampening 0, no nesterov). */
+int y4_adam_hyper_f32(float lr, float beta1, float beta2, float weight_decay, int step, float* out4_host);
+int y4_adam_multi_step_f32(const void* chunks_dev, int nchunks, const float* hyper_host, int nhyper,
+                           float beta1, float beta2, float eps, float grad_scale, void* stream);
+int y4_sgd_multi_step_f32(const void* chunks_dev, int nchunks, const float* hyper_host, int nhyper,
+                          float grad_scale, void* stream);
 
 /* ---------------------------------------------------------------- eval input pipeline ("next" row 4)
  * One image: src is uint8 HWC (3 channels, row pitch in bytes), as cv2.imread hands it to the reference.

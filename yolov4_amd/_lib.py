@@ -67,7 +67,15 @@ PROTOTYPES = {
     'y4_post_nms_f32': (I, [P, I, L, I, F, F, P, L, P, P, P, Z, P]),
     'y4_nms_workspace': (Z, [L]),
     'y4_nms_f32': (I, [P, P, L, F, I, P, P, P, Z, P]),
+    'y4_bboxes_iou_f32': (I, [P, L, P, L, I, P, P]),
+    'y4_act_fwd_f32': (I, [P, P, L, I, P]),
+    'y4_act_bwd_f32': (I, [P, P, P, L, I, P]),
+    'y4_upsample_nearest_fwd_f32': (I, [P, I, P, I, I, I, I, I, I, I, I, P]),
+    'y4_upsample_nearest_bwd_f32': (I, [P, I, P, I, I, I, I, I, I, I, I, P]),
     'y4_adam_step_f32': (I, [P, P, P, P, L, F, F, F, F, F, I, F, P]),
+    'y4_adam_hyper_f32': (I, [F, F, F, F, I, P]),
+    'y4_adam_multi_step_f32': (I, [P, I, P, I, F, F, F, F, P]),
+    'y4_sgd_multi_step_f32': (I, [P, I, P, I, F, P]),
     'y4_preprocess_u8_f32': (I, [P, I, I, L, I, P, L, L, L, I, P]),
 }
 

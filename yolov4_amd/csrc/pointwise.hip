@@ -469,6 +469,102 @@ __global__ __launch_bounds__(PW_THREADS) void upsample2x_bwd_kernel(const float*
     }
 }
 
+// ---------------------------------------------------------------- general nearest upsample (Upsample, yolov4.py:82-90)
+// Source index of destination index d: integer factor f > 0 -> d / f (the eval branch's view/expand/contiguous);
+// otherwise min(floor(d * scale), in - 1) with scale = (float)in / out, the arithmetic of F.interpolate(size=...,
+// mode='nearest') in the train branch (ATen nearest_neighbor_compute_source_index).
+__device__ __forceinline__ int nearest_src(int d, int f, float scale, int n_in) {
+    if (f > 0) return d / f;
+    const int s = (int)floorf((float)d * scale);
+    return s < n_in - 1 ? s : n_in - 1;
+}
+__global__ __launch_bounds__(PW_THREADS) void upsample_nearest_fwd_kernel(const float* __restrict__ x, long long ldx,
+                                                                          float* __restrict__ y, long long ldy,
+                                                                          int B, int H, int W, int Ho, int Wo, int C4,
+                                                                          int fh, int fw, float sh, float sw) {
+    const long long total = (long long)B * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int w = (int)(pix % Wo);
+        const int h = (int)((pix / Wo) % Ho);
+        const long long b = pix / ((long long)Wo * Ho);
+        const int hs = nearest_src(h, fh, sh, H), ws = nearest_src(w, fw, sw, W);
+        st4(y + pix * ldy + c, ld4(x + ((b * H + hs) * W + ws) * ldx + c));
+    }
+}
+// backward: a source pixel gathers the contiguous block of destination pixels that map to it (the map is monotone),
+// summed row-major in a fixed order -> deterministic, no atomics
+__device__ __forceinline__ void nearest_range(int s, int f, float scale, int n_in, int n_out, int& lo, int& hi) {
+    if (f > 0) { lo = s * f; hi = lo + f; if (hi > n_out) hi = n_out; return; }
+    int d = (int)((float)s / scale) - 2;
+    if (d < 0) d = 0;
+    while (d < n_out && nearest_src(d, 0, scale, n_in) < s) ++d;
+    lo = d;
+    while (d < n_out && nearest_src(d, 0, scale, n_in) == s) ++d;
+    hi = d;
+}
+__global__ __launch_bounds__(PW_THREADS) void upsample_nearest_bwd_kernel(const float* __restrict__ dy, long long lddy,
+                                                                          float* __restrict__ dx, long long lddx,
+                                                                          int B, int H, int W, int Ho, int Wo, int C4,
+                                                                          int fh, int fw, float sh, float sw) {
+    const long long total = (long long)B * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long pix = i / C4;
+        const int w = (int)(pix % W);
+        const int h = (int)((pix / W) % H);
+        const long long b = pix / ((long long)W * H);
+        int h0, h1, w0, w1;
+        nearest_range(h, fh, sh, H, Ho, h0, h1);
+        nearest_range(w, fw, sw, W, Wo, w0, w1);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int hh = h0; hh < h1; ++hh)
+            for (int ww = w0; ww < w1; ++ww) s += ld4(dy + ((b * Ho + hh) * Wo + ww) * lddy + c);
+        st4(dx + pix * lddx + c, s);
+    }
+}
+
+// ---------------------------------------------------------------- standalone activation (Mish.forward, darknet.py:14-20)
+// Flat elementwise sweep over a dense tensor of n floats; the same device functions as the fused epilogues.
+__global__ __launch_bounds__(PW_THREADS) void act_fwd_flat_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  long long n, int act) {
+    const long long n4 = n >> 2;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    const long long stride = (long long)gridDim.x * blockDim.x, t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    long long done = 0;
+    if (vec) {
+        for (long long i = t; i < n4; i += stride) {
+            f32x4 v = ld4(x + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = y4_act(v[e], act);
+            st4(y + 4 * i, v);
+        }
+        done = n4 << 2;
+    }
+    for (long long i = done + t; i < n; i += stride) y[i] = y4_act(x[i], act);
+}
+__global__ __launch_bounds__(PW_THREADS) void act_bwd_flat_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, long long n, int act) {
+    const long long n4 = n >> 2;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0;
+    const long long stride = (long long)gridDim.x * blockDim.x, t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    long long done = 0;
+    if (vec) {
+        for (long long i = t; i < n4; i += stride) {
+            const f32x4 v = ld4(x + 4 * i), g = ld4(dy + 4 * i);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = g[e] * y4_act_grad(v[e], act);
+            st4(dx + 4 * i, o);
+        }
+        done = n4 << 2;
+    }
+    for (long long i = done + t; i < n; i += stride) dx[i] = dy[i] * y4_act_grad(x[i], act);
+}
+
 inline int grid_for(long long total, int cap = 256 * 16) {
     long long b = (total + PW_THREADS - 1) / PW_THREADS;
     if (b > cap) b = cap;
@@ -682,6 +778,52 @@ int y4_upsample2x_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int B,
     if (!vec_ok(dy, lddy, C) || !vec_ok(dx, lddx, C) || B <= 0 || H <= 0 || W <= 0) return Y4_ERR_SHAPE;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(PW_THREADS), 0,
                        y4_stream(stream), dy, (long long)lddy, dx, (long long)lddx, B, H, W, C / 4);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_upsample_nearest_fwd_f32(const float* x, int ldx, float* y, int ldy, int B, int H, int W, int Ho, int Wo, int C,
+                                int integer_factor, void* stream) {
+    if (!vec_ok(x, ldx, C) || !vec_ok(y, ldy, C) || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return Y4_ERR_SHAPE;
+    int fh = 0, fw = 0;
+    if (integer_factor) {
+        if (Ho % H || Wo % W) return Y4_ERR_SHAPE;          // the reference's final .view() fails the same way
+        fh = Ho / H; fw = Wo / W;
+    }
+    hipLaunchKernelGGL(upsample_nearest_fwd_kernel, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(PW_THREADS), 0,
+                       y4_stream(stream), x, (long long)ldx, y, (long long)ldy, B, H, W, Ho, Wo, C / 4, fh, fw,
+                       (float)H / (float)Ho, (float)W / (float)Wo);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_upsample_nearest_bwd_f32(const float* dy, int lddy, float* dx, int lddx, int B, int H, int W, int Ho, int Wo, int C,
+                                int integer_factor, void* stream) {
+    if (!vec_ok(dy, lddy, C) || !vec_ok(dx, lddx, C) || B <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0) return Y4_ERR_SHAPE;
+    int fh = 0, fw = 0;
+    if (integer_factor) {
+        if (Ho % H || Wo % W) return Y4_ERR_SHAPE;
+        fh = Ho / H; fw = Wo / W;
+    }
+    hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(PW_THREADS), 0,
+                       y4_stream(stream), dy, (long long)lddy, dx, (long long)lddx, B, H, W, Ho, Wo, C / 4, fh, fw,
+                       (float)H / (float)Ho, (float)W / (float)Wo);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_act_fwd_f32(const float* x, float* y, long long n, int act, void* stream) {
+    if (!x || !y) return Y4_ERR_NULL;
+    if (n <= 0 || act < 0 || act > 3) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(act_fwd_flat_kernel, dim3(grid_for((n + 3) / 4)), dim3(PW_THREADS), 0, y4_stream(stream), x, y, n, act);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_act_bwd_f32(const float* x, const float* dy, float* dx, long long n, int act, void* stream) {
+    if (!x || !dy || !dx) return Y4_ERR_NULL;
+    if (n <= 0 || act < 0 || act > 3) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(act_bwd_flat_kernel, dim3(grid_for((n + 3) / 4)), dim3(PW_THREADS), 0, y4_stream(stream), x, dy, dx, n, act);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -80,6 +80,38 @@ __global__ __launch_bounds__(256) void yolo_decode_bwd_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------ pairwise IoU
+// bboxes_iou, yolo/model/yololoss.py:16-91: [Na,4] x [Nb,4] -> [Na,Nb]; xyxy corners or centre/size; the intersection
+// counts only where tl < br on both axes; area_i / (area_a + area_b - area_i), no epsilon.  torch.max/min
+// propagate NaN (fmaxf/fminf do not), kept here.  One thread per (a, b) pair, the fp32 operation sequence of the
+// reference (this file is built with -ffp-contract=off).
+__device__ __forceinline__ float tmax_(float a, float b) { return (a != a || b != b) ? NAN : fmaxf(a, b); }
+__device__ __forceinline__ float tmin_(float a, float b) { return (a != a || b != b) ? NAN : fminf(a, b); }
+__global__ __launch_bounds__(256) void bboxes_iou_kernel(const float* __restrict__ A_, long long Na, const float* __restrict__ B_,
+                                                         long long Nb, int xyxy, float* __restrict__ out) {
+    const long long total = Na * Nb;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long ia = i / Nb, ib = i - ia * Nb;
+        const float a0 = A_[ia * 4], a1 = A_[ia * 4 + 1], a2 = A_[ia * 4 + 2], a3 = A_[ia * 4 + 3];
+        const float b0 = B_[ib * 4], b1 = B_[ib * 4 + 1], b2 = B_[ib * 4 + 2], b3 = B_[ib * 4 + 3];
+        float tlx, tly, brx, bry, area_a, area_b;
+        if (xyxy) {
+            tlx = tmax_(a0, b0); tly = tmax_(a1, b1);
+            brx = tmin_(a2, b2); bry = tmin_(a3, b3);
+            area_a = (a2 - a0) * (a3 - a1);
+            area_b = (b2 - b0) * (b3 - b1);
+        } else {
+            tlx = tmax_(a0 - a2 / 2.f, b0 - b2 / 2.f); tly = tmax_(a1 - a3 / 2.f, b1 - b3 / 2.f);
+            brx = tmin_(a0 + a2 / 2.f, b0 + b2 / 2.f); bry = tmin_(a1 + a3 / 2.f, b1 + b3 / 2.f);
+            area_a = a2 * a3;
+            area_b = b2 * b3;
+        }
+        const float en = ((tlx < brx) ? 1.f : 0.f) * ((tly < bry) ? 1.f : 0.f);
+        const float area_i = ((brx - tlx) * (bry - tly)) * en;
+        out[i] = area_i / ((area_a + area_b) - area_i);
+    }
+}
+
 // ------------------------------------------------------------------------------------ loss
 struct LossWs {
     size_t nlabel, npos, truth, pos_cell, pos_val, pos_cls, pos_index, partials, total;
@@ -609,6 +641,19 @@ static bool fill_anchors(Anchors& a, const float* host_wh, int n) {
 }  // namespace
 
 extern "C" {
+
+int y4_bboxes_iou_f32(const float* boxes_a, long long Na, const float* boxes_b, long long Nb, int xyxy, float* iou,
+                      void* stream) {
+    if (Na < 0 || Nb < 0) return Y4_ERR_SHAPE;
+    if (Na == 0 || Nb == 0) return Y4_OK;
+    if (!boxes_a || !boxes_b || !iou) return Y4_ERR_NULL;
+    long long blocks = (Na * Nb + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bboxes_iou_kernel, dim3((unsigned)blocks), dim3(256), 0, y4_stream(stream), boxes_a, Na, boxes_b, Nb,
+                       xyxy, iou);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
 
 int y4_yolo_decode_train_f32(const float* logits, int ldl, float* output, float* pred,
                              int B, int F, int A, int n_classes, const float* anchors_wh_host, void* stream) {

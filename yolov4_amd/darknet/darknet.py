@@ -16,10 +16,12 @@ from .. import ops
 
 
 class Mish(nn.Module):
-    """x * tanh(softplus(x)); marker module -- the arithmetic is fused into the library kernels."""
+    """x * tanh(softplus(x)), darknet/darknet.py:14-20.  Inside ConvBNAct the arithmetic is fused into the BN / conv
+    epilogue kernels (this module is then only a marker); called on its own it runs the same device function as a
+    flat elementwise kernel (y4_act_fwd_f32 / y4_act_bwd_f32)."""
 
     def forward(self, x):
-        raise ops.Y4Error('Mish is fused into ConvBNAct on this path and has no standalone kernel')
+        return ops.ActFn.apply(x, 'mish')
 
 
 _ACT_MODULES = {

@@ -11,22 +11,38 @@ all-reduce is issued on RCCL's own stream as soon as its last wgrad has been
 enqueued, so the exchange runs under the remaining dgrad/wgrad kernels.  One process
 per GPU, `torch.distributed` backend "nccl" (= RCCL on ROCm); "gloo" is supported for
 the CPU tests of the bucket logic.
+
+Drop-in: the swap at main_amp.py:131 is one line,
+
+    model = BucketedDDP(model)          # was: DDP(model, delay_allreduce=True)
+
+and the reference's loop (yolo/engine/build.py:53-69: optimizer.zero_grad(); output = model(input);
+loss.backward(); optimizer.step(); optimizer.zero_grad()) runs unchanged: `forward` re-arms the buckets and
+heals the gradient slots (an `optimizer.zero_grad()` with torch's default set_to_none=True detaches
+`p.grad` from the flat buffers), the first gradient hook of a backward queues an end-of-backward
+callback that waits for the exchanges.  `zero_grad()`, `rearm()` and `finish_backward()` remain
+callable (idempotent) for explicit control, e.g. gradient accumulation without exchange.
 """
 import torch
 import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ('flat', 'params', 'pending', 'work', 'launched')
+    __slots__ = ('flat', 'params', 'views', 'pending', 'work', 'launched')
 
-    def __init__(self, flat, params):
-        self.flat, self.params = flat, params
+    def __init__(self, flat, params, views):
+        self.flat, self.params, self.views = flat, params, views
         self.pending, self.work, self.launched = 0, None, False
+
+
+def _align(n, a):
+    return (n + a - 1) // a * a
 
 
 class BucketedDDP(torch.nn.Module):
 
-    def __init__(self, module, bucket_mb=25.0, process_group=None, broadcast=True):
+    def __init__(self, module, bucket_mb=25.0, process_group=None, broadcast=True, delay_allreduce=True, **_apex_kw):
+        """delay_allreduce / other apex keyword arguments are accepted for call compatibility and ignored."""
         super().__init__()
         self.module = module
         self.pg = process_group
@@ -49,6 +65,9 @@ class BucketedDDP(torch.nn.Module):
         if cur:
             self.buckets.append(self._make_bucket(cur))
         self.accumulating = False     # set True for all but the last micro-step of an accumulation window
+        self._in_backward = False     # an end-of-backward callback is queued
+        self._finished = True         # finish_backward() ran for the last backward
+        self.stats = {'healed': 0, 'copied_in': 0}      # slots re-attached / stray gradients copied in (diagnostics)
         self._hooks = []
         for b in self.buckets:
             for p in b.params:
@@ -56,6 +75,7 @@ class BucketedDDP(torch.nn.Module):
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))
                 # gradients produced outside autograd (yolov4_amd.ops: wgrad on the side stream) report here
                 p._y4_grad_ready = (lambda h=hook, q=p: h(q))
+                p._y4_ddp = self
         self.zero_grad()
 
     # -- setup
@@ -72,28 +92,61 @@ class BucketedDDP(torch.nn.Module):
                     o += t.numel()
 
     @staticmethod
-    def _make_bucket(params):
+    def _slot_view(flat, o, p):
+        # the gradient of a KRSC (channels_last) filter keeps that memory layout inside the flat buffer
+        g = flat[o:o + p.numel()]
+        if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+            Co, Ci, kh, kw = p.shape
+            return g.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
+        return g.view(p.shape)
+
+    @classmethod
+    def _make_bucket(cls, params):
         dev, dt = params[0].device, params[0].dtype
-        flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=dt)
-        o = 0
+        # every slot starts on a 16-byte boundary (the conv kernels write filter gradients with 16-B stores; the
+        # three 255-element head biases would otherwise leave all later slots misaligned); the pad words stay zero
+        offs, o = [], 0
         for p in params:
-            # the gradient of a KRSC (channels_last) filter keeps that memory layout inside the flat buffer
-            g = flat[o:o + p.numel()]
-            if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
-                Co, Ci, kh, kw = p.shape
-                g = g.view(Co, kh, kw, Ci).permute(0, 3, 1, 2)
-            else:
-                g = g.view(p.shape)
+            offs.append(o)
+            o = _align(o + p.numel(), 4)
+        flat = torch.zeros(o, device=dev, dtype=dt)
+        views = []
+        for p, off in zip(params, offs):
+            g = cls._slot_view(flat, off, p)
             p.grad = g
-            o += p.numel()
-        return _Bucket(flat, list(params))
+            views.append(g)
+        return _Bucket(flat, list(params), views)
 
     def _make_hook(self, bucket):
-        def hook(_param):
+        index = {id(p): i for i, p in enumerate(bucket.params)}
+
+        def hook(param):
+            if not self._in_backward:
+                self._begin_backward()
+            # a gradient that does not live in its slot (p.grad was None or replaced after forward): move it in
+            g, v = param.grad, bucket.views[index[id(param)]]
+            if g is not None and (g.data_ptr() != v.data_ptr() or g.stride() != v.stride()):
+                with torch.no_grad():
+                    v.copy_(g)
+                param.grad = v
+                self.stats['copied_in'] += 1
             bucket.pending -= 1
             if bucket.pending == 0 and not self.accumulating:
                 self._launch(bucket)
         return hook
+
+    def _begin_backward(self):
+        self._in_backward = True
+        self._finished = False
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        except RuntimeError:
+            # not inside a backward pass (gradient reported by hand): the caller runs finish_backward()
+            self._in_backward = False
+
+    def _end_of_backward(self):
+        self._in_backward = False
+        self.finish_backward()
 
     def _launch(self, b):
         if b.launched or not self.use_dist:
@@ -121,26 +174,57 @@ class BucketedDDP(torch.nn.Module):
         return sts
 
     # -- per step
-    def zero_grad(self, set_to_none=False):
+    def _heal(self):
+        """Re-attach every gradient slot that was detached from its flat buffer (p.grad set to None by
+        optimizer.zero_grad(set_to_none=True), torch's default, or replaced by a foreign tensor).  A detached slot
+        means "this gradient is zero": the slot is cleared and may then be written in place by the producing kernel."""
         for b in self.buckets:
-            b.flat.zero_()
-            for p in b.params:
+            lost = [i for i, p in enumerate(b.params)
+                    if p.grad is None or p.grad.data_ptr() != b.views[i].data_ptr() or p.grad.stride() != b.views[i].stride()]
+            if not lost:
+                continue
+            with torch.no_grad():
+                if len(lost) == len(b.params):
+                    b.flat.zero_()
+                else:
+                    for i in lost:
+                        b.views[i].zero_()
+            for i in lost:
+                p = b.params[i]
+                p.grad = b.views[i]
+                p._y4_grad_fresh = True
+            self.stats['healed'] += len(lost)
+
+    def zero_grad(self, set_to_none=False):
+        """Clears the flat buckets (one memset each) and re-arms them; gradients stay views of the buckets."""
+        for b in self.buckets:
+            with torch.no_grad():
+                b.flat.zero_()
+            for i, p in enumerate(b.params):
+                p.grad = b.views[i]
                 # a zeroed slot may be written in place by the producing kernel (yolov4_amd.ops.ConvBNActFn)
-                p._y4_grad_fresh = p.grad is not None
+                p._y4_grad_fresh = True
         self.rearm()
 
     def rearm(self):
-        """Before every backward of an accumulation window after the first (gradients keep accumulating
-        in the flat buckets; yolo/engine/build.py:56-69 steps every ACCUMULATION_STEPS micro-batches)."""
+        """Before every backward (forward() does it): gradients keep accumulating in the flat buckets across the
+        micro-steps of an accumulation window (yolo/engine/build.py:56-69 steps every ACCUMULATION_STEPS)."""
         for b in self.buckets:
             b.pending, b.work, b.launched = len(b.params), None, False
 
     def forward(self, *a, **kw):
+        if torch.is_grad_enabled() and self.module.training:
+            self._heal()
+            self.rearm()
         return self.module(*a, **kw)
 
     def finish_backward(self):
-        """Call after loss.backward(): waits for the bucket exchanges (stream-wise: the current stream
-        waits for RCCL's) and applies the 1/world average where the backend has no AVG."""
+        """Waits for the bucket exchanges (stream-wise: the current stream waits for RCCL's) and applies the
+        1/world average where the backend has no AVG.  Runs by itself at the end of every backward (autograd
+        callback); calling it again afterwards is a no-op."""
+        if self._finished:
+            return
+        self._finished = True
         if self.buckets and self.buckets[0].flat.is_cuda:
             from . import ops
             ops.join_side_stream()
@@ -153,3 +237,4 @@ class BucketedDDP(torch.nn.Module):
                 b.work.wait()
                 if self.backend != 'nccl':
                     b.flat.div_(self.world)
+                b.work = None

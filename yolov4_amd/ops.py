@@ -198,8 +198,15 @@ def conv_dgrad_raw(dy, w, x_shape, k, s):
 
 
 def _is_krsc_dense(t):
+    """Dense KRSC memory; strides of size-1 dims are irrelevant (a 1x1 filter slot of a flat gradient bucket is a
+    plain [Co, Ci, 1, 1] view whose kh/kw strides read 1)."""
     Co, Ci, kh, kw = t.shape
-    return t.dtype == torch.float32 and t.stride() == (kh * kw * Ci, 1, kw * Ci, Ci)
+    exp = (kh * kw * Ci, 1, kw * Ci, Ci)
+    st = t.stride()
+    return t.dtype == torch.float32 and all(t.shape[i] == 1 or st[i] == exp[i] for i in range(4))
+
+
+WGRAD_STATS = {'in_place': 0, 'temporary': 0}      # filter gradients written into a caller slot vs a temporary
 
 
 def conv_wgrad_raw(x, dy, w_shape, k, s, out=None):
@@ -210,7 +217,9 @@ def conv_wgrad_raw(x, dy, w_shape, k, s, out=None):
     Cout = w_shape[0]
     if out is not None and tuple(out.shape) == tuple(w_shape) and _is_krsc_dense(out) and out.data_ptr() % 16 == 0:
         dw = out
+        WGRAD_STATS['in_place'] += 1
     else:
+        WGRAD_STATS['temporary'] += 1
         dw = torch.empty(w_shape, device=dy.device, dtype=torch.float32).contiguous(memory_format=CL)
         dw = krsc(dw)
     if Cin == 3:
@@ -391,7 +400,12 @@ class ConvBNActFn(torch.autograd.Function):
         k, s, act, training, bn = cfg['k'], cfg['s'], cfg['act'], cfg['training'], cfg['bn']
         _require_gpu(x, 'ConvBNAct input')
         _require_gpu(weight, 'ConvBNAct weight')
-        ctx.cfg = cfg
+        # The destination slot is handed in through cfg but must NOT stay reachable from ctx: forward returns that
+        # very tensor, so output -> grad_fn -> ctx -> cfg['out'] -> output would be a reference cycle that only a
+        # full gc.collect() breaks (round 1: +4.96 GiB of concat buffers per training step).  ctx keeps the
+        # scalars and parameter handles backward needs, nothing else.
+        dest = cfg.pop('out', None)
+        ctx.cfg = {key: cfg.get(key) for key in ('k', 's', 'act', 'gamma_param', 'beta_param', 'weight_param')}
         ctx.x_shape = tuple(x.shape)
         ctx.has_res = residual is not None
         if bn and training:
@@ -399,12 +413,12 @@ class ConvBNActFn(torch.autograd.Function):
                 raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
             y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
                                                    cfg['nbt'], cfg['momentum'], cfg['eps'])
-            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=cfg.get('out'))
+            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest)
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
         elif bn:
             scale, shift = bn_fold_raw(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
-            o = cfg.get('out')
+            o = dest
             Ho, Wo = conv_out_hw(x.shape[2], x.shape[3], k, s)
             z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual,
                              out=o if _slot_ok(o, (x.shape[0], weight.shape[0], Ho, Wo)) else None)
@@ -633,6 +647,84 @@ class Upsample2xFn(torch.autograd.Function):
         dx = empty_nhwc(B, C, H, W, g.device)
         check(L.y4_upsample2x_bwd_f32(_ptr(g), ldg, _ptr(dx), nhwc_pitch(dx), B, H, W, C, _stream()), 'upsample_bwd')
         return dx, None
+
+
+class UpsampleNearestFn(torch.autograd.Function):
+    """Upsample.forward for any target size, yolo/model/yolov4.py:82-90: the train branch is
+    F.interpolate(size=target, mode='nearest'), the eval branch an integer-factor expand."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, integer_factor, out=None):
+        L = lib()
+        _require_gpu(x, 'upsample input')
+        B, C, H, W = x.shape
+        x, ldx = as_nhwc(x)
+        dst = out.t if (out is not None and _slot_ok(out.t, (B, C, Ho, Wo))) else empty_nhwc(B, C, Ho, Wo, x.device)
+        check(L.y4_upsample_nearest_fwd_f32(_ptr(x), ldx, _ptr(dst), nhwc_pitch(dst), B, H, W, Ho, Wo, C,
+                                            1 if integer_factor else 0, _stream()), 'upsample_nearest')
+        ctx.meta = (B, C, H, W, Ho, Wo, integer_factor)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        L = lib()
+        B, C, H, W, Ho, Wo, integer_factor = ctx.meta
+        g, ldg = as_nhwc(g)
+        dx = empty_nhwc(B, C, H, W, g.device)
+        check(L.y4_upsample_nearest_bwd_f32(_ptr(g), ldg, _ptr(dx), nhwc_pitch(dx), B, H, W, Ho, Wo, C,
+                                            1 if integer_factor else 0, _stream()), 'upsample_nearest_bwd')
+        return dx, None, None, None, None
+
+
+def _dense(t):
+    """t if its memory is one dense block (any dim order), else a contiguous copy."""
+    if t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=CL)):
+        return t
+    if t.numel() and t.is_non_overlapping_and_dense():
+        return t
+    return t.contiguous()
+
+
+class ActFn(torch.autograd.Function):
+    """Stand-alone activation (Mish.forward, darknet/darknet.py:14-20): flat elementwise sweep."""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        L = lib()
+        _require_gpu(x, f'{act} input')
+        x = _dense(x)
+        y = torch.empty_like(x, memory_format=torch.preserve_format)
+        if x.numel():
+            check(L.y4_act_fwd_f32(_ptr(x), _ptr(y), x.numel(), ACT_IDS[act], _stream()), 'act_fwd')
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        L = lib()
+        (x,) = ctx.saved_tensors
+        if g.stride() != x.stride():
+            g = torch.empty_like(x, memory_format=torch.preserve_format).copy_(g)
+        dx = torch.empty_like(x, memory_format=torch.preserve_format)
+        if x.numel():
+            check(L.y4_act_bwd_f32(_ptr(x), _ptr(g), _ptr(dx), x.numel(), ACT_IDS[ctx.act], _stream()), 'act_bwd')
+        return dx, None
+
+
+def bboxes_iou_raw(a, b, xyxy=True):
+    """bboxes_iou, yolo/model/yololoss.py:16-91 (no gradient: the reference only uses it on detached boxes)."""
+    L = lib()
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != 4 or b.shape[1] != 4:
+        raise IndexError                                    # yololoss.py:39-40
+    _require_gpu(a, 'bboxes_iou boxes_a')
+    _require_gpu(b, 'bboxes_iou boxes_b')
+    a = a.detach().contiguous()
+    b = b.detach().contiguous()
+    out = torch.empty((a.shape[0], b.shape[0]), device=a.device, dtype=torch.float32)
+    check(L.y4_bboxes_iou_f32(_ptr(a), a.shape[0], _ptr(b), b.shape[0], 1 if xyxy else 0, _ptr(out), _stream()),
+          'bboxes_iou')
+    return out
 
 
 class Slot:

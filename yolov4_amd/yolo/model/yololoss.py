@@ -12,8 +12,9 @@ from ... import ops
 
 
 def bboxes_iou(bboxes_a, bboxes_b, xyxy=True):
-    raise ops.Y4Error('bboxes_iou is fused into the target-assignment / ignore-mask kernels on this path '
-                      '(y4_yolo_loss_fwd_f32); no standalone pairwise-IoU kernel is exported')
+    """Pairwise IoU [Na,4] x [Nb,4] -> [Na,Nb] (yololoss.py:16-91) as one HIP kernel (y4_bboxes_iou_f32).  The loss
+    path does not call it: target assignment and the ignore mask carry the same arithmetic inlined."""
+    return ops.bboxes_iou_raw(bboxes_a, bboxes_b, xyxy)
 
 
 class YOLOLoss(nn.Module):

@@ -63,10 +63,18 @@ class SPPBlock(nn.Module):
 class Upsample(nn.Module):
 
     def forward(self, x, target_size, out=None):
+        """out: optional destination (a CatBuffer slot); the reference has no such argument."""
         assert x.dim() == 4
-        if target_size[2] != 2 * x.shape[2] or target_size[3] != 2 * x.shape[3]:
-            raise ops.Y4Error('Upsample: only the exact x2 nearest case of the YOLOv4 neck is implemented')
-        return ops.Upsample2xFn.apply(x, ops.Slot(out) if out is not None else None)
+        slot = ops.Slot(out) if out is not None else None
+        Ht, Wt = int(target_size[2]), int(target_size[3])
+        if Ht == 2 * x.shape[2] and Wt == 2 * x.shape[3]:
+            return ops.Upsample2xFn.apply(x, slot)                 # the YOLOv4 neck at S % 32 == 0
+        # any other target (e.g. S = 600: 19 -> 38 -> 75): train = F.interpolate(size=target, nearest) (yolov4.py:85);
+        # eval = integer-factor expand whose final view() needs target % input == 0 (yolov4.py:87-90)
+        if not self.training and (Ht % x.shape[2] or Wt % x.shape[3]):
+            raise RuntimeError(f"shape '[{x.shape[0]}, {x.shape[1]}, {Ht}, {Wt}]' is invalid for input of size "
+                               f"{x.shape[0] * x.shape[1] * (Ht // x.shape[2]) * x.shape[2] * (Wt // x.shape[3]) * x.shape[3]}")
+        return ops.UpsampleNearestFn.apply(x, Ht, Wt, not self.training, slot)
 
 
 class FPNBlock(nn.Module):
