@@ -56,7 +56,16 @@ int y4_device_count(void);
  *   0  v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fp32 fma chain.
  *   2  plain bf16: operands rounded (RN) to bf16 while staged, one bf16 MFMA per product, fp32
  *      accumulate; activations / gradients / BN / loss / NMS stay fp32 (BASELINE config 5, mixed
- *      precision -- NOT fp32-grade: ~3 significant digits per product). */
+ *      precision -- NOT fp32-grade: ~3 significant digits per product).
+ *   3  "f16x2": every fp32 operand is scaled by a power of two taken from its tensor's max|x| (so the
+ *      maximum lands in [2^14, 2^15)) and split into two fp16 pieces hi = RN(sx), lo = RN((sx-hi) 2^11)
+ *      (11 + 11 significant bits, |error| <= 2^-22 |x|); a product is THREE fp16 MFMAs
+ *      (hi*hi -> acc0; hi*lo + lo*hi -> acc1; result (acc0 + 2^-11 acc1)/(s_a s_b)), fp32 accumulate.
+ *      Per-product error ~2^-22, i.e. 2.4e-7 of the rms of a sum of any length: below the rounding of
+ *      an fp32 fma chain and of the MFMA's own fp32 accumulation; half the MFMAs of mode 1.  Operand
+ *      maxima (`*_amax` arguments: device words holding the bit pattern of max|finite element|,
+ *      upper bounds are fine) come from the producing kernels (y4_bn_act_fwd_f32 / y4_bn_act_bwd_f32
+ *      out_amax) or, when NULL, from one extra pass over the operand inside the call. */
 int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
 /* Scratch arena for library temporaries whose size depends only on the layer (the pre-split filter
@@ -81,7 +90,12 @@ int y4_set_workspace(void* ptr, size_t bytes);
 int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                       int B, int H, int W, int Cin, int Cout, int k, int stride,
                       const float* scale, const float* shift, int act,
-                      const float* residual, int ldr, void* stream);
+                      const float* residual, int ldr, const unsigned* x_amax /* mode 3, nullable */, void* stream);
+/* max |finite element| over the first C channels of an NHWC tensor (pitch ldx), as a bit pattern (mode 3 operand
+ * maximum).  y4_amax_f32 overwrites *amax_bits; y4_amax_merge_u32 folds *src into *dst (a concat buffer's maximum is
+ * the maximum of its parts).  Integer atomicMax: order independent. */
+int y4_amax_f32(const float* x, int ldx, long long M, int C, unsigned* amax_bits, void* stream);
+int y4_amax_merge_u32(unsigned* dst, const unsigned* src, void* stream);
 
 /* Training-mode variant: raw conv output + BatchNorm batch statistics fused into the epilogue.
  * partials receives one row [2][Cout] (column sums, sums of squares) per M-tile; *nparts_host
@@ -90,7 +104,8 @@ int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy
 size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                               int B, int H, int W, int Cin, int Cout, int k, int stride,
-                              float* partials, size_t partial_bytes, long long* nparts_host, void* stream);
+                              float* partials, size_t partial_bytes, long long* nparts_host,
+                              const unsigned* x_amax /* mode 3, nullable */, void* stream);
 
 /* Stem conv (Cin = 3): x addressed as x[b*sxb + c*sxc + h*sxh + w*sxw] so both the NCHW
  * tensor the reference feeds (yolo/engine/build.py:60) and NHWC work without a copy.
@@ -101,19 +116,23 @@ int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long lo
                            const float* scale, const float* shift, int act,
                            float* bnstats_partials, void* stream);
 
-/* dgrad: dx[B,H,W,Cin] = conv_transpose(dy[B,Ho,Wo,Cout], w) -- autograd of nn.Conv2d wrt input.
- * workspace: y4_conv2d_dgrad_workspace() bytes (holds the [Cin][k][k][Cout4] transposed filter). */
+/* dgrad: dx[B,H,W,Cin] = conv_transpose(dy[B,Ho,Wo,Cout], w) (+ residual) -- autograd of nn.Conv2d wrt input.
+ * workspace: y4_conv2d_dgrad_workspace() bytes (holds the [Cin][k][k][Cout4] transposed filter).
+ * residual (nullable, pitch ldr >= Cin): added in the epilogue -- the gradient arriving over a ResBlock's skip
+ * connection (darknet/darknet.py:76-80: x + f(x)), so the fan-in add costs no extra pass. */
 size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k);
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes, const unsigned* dy_amax /* mode 3, nullable */,
+                        const float* residual, int ldr, void* stream);
 
 /* wgrad: dw[Cout][k][k][Cin] = sum_{b,ho,wo} dy (x) x -- autograd of nn.Conv2d wrt weight.
  * Split-K over pixels into fp32 slabs in `workspace`, reduced in a fixed order (deterministic). */
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        void* workspace, size_t workspace_bytes,
+                        const unsigned* x_amax, const unsigned* dy_amax /* mode 3, nullable */, void* stream);
 size_t y4_conv2d_stem_wgrad_workspace(int B, int H, int W, int Cout);
 int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
                              const float* dy, int lddy, float* dw, int B, int H, int W, int Cout,

@@ -4,7 +4,10 @@ import sys, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import torch
+import yolov4_amd
 from yolov4_amd import ops
+if os.environ.get('CONV_MODE'):
+    yolov4_amd.set_conv_mode(os.environ['CONV_MODE'])
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 kinds = sys.argv[2].split(',') if len(sys.argv) > 2 else ['fwd', 'dgrad', 'wgrad']
 only = sys.argv[3] if len(sys.argv) > 3 else None

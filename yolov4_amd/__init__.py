@@ -23,7 +23,7 @@ def set_conv_mode(mode):
     """0 / 'f32': fp32 MFMA (exact fma chain).  1 / 'bf16x3': exact 3-way bf16 split, six bf16 MFMAs
     per product, fp32 accumulate (fp32-grade error, see include/yolov4_amd.h)."""
     from ._lib import check
-    m = {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(mode, mode)
+    m = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x2': 3}.get(mode, mode)
     check(lib().y4_set_conv_mode(int(m)), 'set_conv_mode')
 
 

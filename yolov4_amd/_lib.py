@@ -30,14 +30,16 @@ PROTOTYPES = {
     'y4_set_conv_mode': (I, [I]),
     'y4_get_conv_mode': (I, []),
     'y4_set_workspace': (I, [P, Z]),
-    'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P]),
+    'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P]),
+    'y4_amax_f32': (I, [P, I, L, I, P, P]),
+    'y4_amax_merge_u32': (I, [P, P, P]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
-    'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P]),
+    'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P]),
     'y4_conv2d_stem_fwd_f32': (I, [P, L, L, L, L, P, P, I, I, I, I, I, P, P, I, P, P]),
     'y4_conv2d_dgrad_workspace': (Z, [I, I, I]),
-    'y4_conv2d_dgrad_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P]),
+    'y4_conv2d_dgrad_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, I, P]),
     'y4_conv2d_wgrad_workspace': (Z, [I, I, I, I, I, I, I]),
-    'y4_conv2d_wgrad_f32': (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, Z, P]),
+    'y4_conv2d_wgrad_f32': (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, Z, P, P, P]),
     'y4_conv2d_stem_wgrad_workspace': (Z, [I, I, I, I]),
     'y4_conv2d_stem_wgrad_f32': (I, [P, L, L, L, L, P, I, P, I, I, I, I, P, Z, P]),
     'y4_bn_workspace': (Z, [L, I]),

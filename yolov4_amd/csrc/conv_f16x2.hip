@@ -1,0 +1,812 @@
+// Implicit-GEMM convolution on the fp16 matrix cores with a two-piece operand split ("f16x2"), gfx950 only.
+//
+// Arithmetic.  The reference computes in fp32.  Every fp32 operand x of a tensor T is first scaled by a
+// power of two s_T (exact) chosen from max|T| so that max|s_T x| lies in [2^14, 2^15), then split into two fp16 pieces
+//     hi = RN16(s x),    lo = RN16((s x - hi) * 2^11)          (s x - hi is exact in fp32)
+// so that s x = hi + 2^-11 lo + e with |e| <= 2^-22 |s x| (11 + 11 significant bits, round to nearest both times).
+// A product is three fp16 MFMAs with exact products and fp32 accumulation,
+//     acc0 += a_hi b_hi          acc1 += a_hi b_lo + a_lo b_hi          c = (acc0 + 2^-11 acc1) / (s_A s_B),
+// dropping a_lo b_lo 2^-22: relative error per product ~2^-22 (random sign), i.e. 2.4e-7 of the rms of the sum for any
+// K -- below the rounding of an fp32 fma chain of the same length (1.2e-6 at K = 4608) and of the accumulation inside
+// the MFMA itself.  The second accumulator keeps the low pieces at full fp16 precision down to |x| = 2^-29 max|T|
+// (hi normal), below which precision degrades gradually to an absolute floor of 2^-50 max|T|.  Half the MFMAs of the
+// 3-piece bf16 split (3 instead of 6), 2 staged planes instead of 3, 3.5 VALU per staged element instead of 5.5.
+//
+// Structure (forward / dgrad "gather" kernel and wgrad): 128x128 (or 64x128, 128x64, 128x32) tile, 4 waves, wave tile
+// of 32x32x16 or 16x16x32 MFMA tiles, LDS rows of 32 k-values = 64 B unpadded with an XOR swizzle of the 16-B chunks
+// chosen per MFMA shape so that every ds_read_b128 lane group is conflict-free, TWO LDS stages and one barrier per
+// K-tile: [barrier] split + write tile t+1 into the other stage, issue the global loads of tile t+2, MFMAs of tile t.
+#include <stdlib.h>
+#include "common.h"
+#include "conv_geom.h"
+
+namespace {
+
+using y4::ConvGeom;
+using y4::WgradGeom;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// ---- operand scale: power of two s with max|T| * s in [2^14, 2^15); amax_bits = bit pattern of max|finite x|
+__device__ __host__ __forceinline__ unsigned f16x2_scale_exp(unsigned amax_bits) {
+    const unsigned e = (amax_bits >> 23) & 0xffu;
+    if (e == 0u || e == 255u) return 127u;                 // all-zero / subnormal / unknown tensor: s = 1
+    int se = 268 - (int)e;                                 // 127 + 14 - (e - 127)
+    if (se < 2) se = 2;
+    if (se > 252) se = 252;
+    return (unsigned)se;
+}
+__device__ __forceinline__ float f16x2_scale(const unsigned* amax) {
+    return __uint_as_float(f16x2_scale_exp(amax ? *amax : 0u) << 23);
+}
+__device__ __forceinline__ float f16x2_unscale(const unsigned* amax) {
+    return __uint_as_float((254u - f16x2_scale_exp(amax ? *amax : 0u)) << 23);
+}
+
+// 4 consecutive fp32 values -> 4 hi halfs (hi[0..1]) and 4 scaled lo halfs
+__device__ __forceinline__ void split2x4(const f32x4 v, const float s, u32x2& hi, u32x2& lo) {
+    f16x2v h01, h23, l01, l23;
+    const float x0 = v[0] * s, x1 = v[1] * s, x2 = v[2] * s, x3 = v[3] * s;
+    h01[0] = (_Float16)x0; h01[1] = (_Float16)x1; h23[0] = (_Float16)x2; h23[1] = (_Float16)x3;
+    const float r0 = x0 - (float)h01[0], r1 = x1 - (float)h01[1], r2 = x2 - (float)h23[0], r3 = x3 - (float)h23[1];
+    l01[0] = (_Float16)(r0 * 2048.f); l01[1] = (_Float16)(r1 * 2048.f);
+    l23[0] = (_Float16)(r2 * 2048.f); l23[1] = (_Float16)(r3 * 2048.f);
+    hi[0] = __builtin_bit_cast(unsigned, h01); hi[1] = __builtin_bit_cast(unsigned, h23);
+    lo[0] = __builtin_bit_cast(unsigned, l01); lo[1] = __builtin_bit_cast(unsigned, l23);
+}
+__device__ __forceinline__ void split2(const float x, const float s, unsigned short& hi, unsigned short& lo) {
+    const float xs = x * s;
+    const _Float16 h = (_Float16)xs;
+    const _Float16 l = (_Float16)((xs - (float)h) * 2048.f);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+}
+
+// ---- LDS image: rows of 32 fp16 (64 B = four 16-B chunks), unpadded.  Chunk c of row r lives at chunk c ^ swz(r).
+//   32x32x16: a 16-lane ds_read_b128 group reads 16 rows (r mod 4 each residue 4 times) at one chunk: XOR with
+//             (r >> 2) & 3 spreads every residue class over the four chunks.
+//   16x16x32: a group reads rows {0-3,12-15} at chunk q and rows {4-11} at chunk q ^ 1 (or the mirrored set):
+//             XOR with g[(r >> 2) & 3], g = {0, 2, 3, 1}, makes the 16 (residue, chunk) slots distinct.
+template <int MS>
+__device__ __forceinline__ int lds_swz(int row) {
+    const int q = (row >> 2) & 3;
+    if constexpr (MS == 32) return q;
+    else return (0x78 >> (2 * q)) & 3;                     // {0, 2, 3, 1}[q] packed two bits each: 0b01'11'10'00
+}
+
+constexpr int ROWB = 64;                                   // bytes per LDS row (32 fp16)
+
+// ==================================================================================== forward / dgrad
+// TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
+// TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
+template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int MS>
+__global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
+    constexpr int BK = 32;
+    constexpr int PA = BM / 32;
+    constexpr int NB = (BN * 4 + 255) / 256;               // 16-B chunks of the B tile per thread and plane
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / MS, TN = WTN / MS;
+    constexpr int ACCN = MS == 32 ? 16 : 4;
+    constexpr int STAGE = 2 * (BM + BN) * ROWB;            // bytes per LDS stage (2 planes of A and B)
+    static_assert(WM * WN == 4, "4 waves");
+    typedef float accv __attribute__((ext_vector_type(ACCN)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    int* row_m = reinterpret_cast<int*>(smem_b + 2 * STAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    int r0 = 0, q0 = 0, tstep = 1;
+    int ph = 0, pw = 0, mt_local, nt;
+    const bool classed = TRANSPOSED && g.stride == 2;
+    if (!classed) {
+        const int lt = y4_xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+        mt_local = lt / g.ntiles;
+        nt = lt - mt_local * g.ntiles;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        int c = 0;
+        while (c < 3 && slot >= g.cls_slot0[c + 1]) ++c;
+        const int per = g.cls_slot0[c + 1] - g.cls_slot0[c];
+        const int t = xcd * per + (slot - g.cls_slot0[c]);
+        const int tiles_c = (g.cls_tile0[c + 1] - g.cls_tile0[c]) * g.ntiles;
+        if (t >= tiles_c) return;                          // padding slot (whole block, before any barrier)
+        mt_local = t / g.ntiles;
+        nt = t - mt_local * g.ntiles;
+        ph = (3 - c) >> 1; pw = (3 - c) & 1;
+        r0 = (ph + g.pad) & 1; q0 = (pw + g.pad) & 1; tstep = 2;
+    }
+    const int n0 = nt * BN;
+    const int nr = (g.k - r0 + tstep - 1) / tstep, nq = (g.k - q0 + tstep - 1) / tstep;
+    const int lrow = tid >> 3, kc = tid & 7;
+
+    const int pix_per_img = classed ? g.cls_h[ph] * g.cls_w[pw] : g.Hd * g.Wd;
+    const int b_first = (int)(((long long)mt_local * BM) / pix_per_img);
+    const unsigned long long img_bytes = (unsigned long long)g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull;
+    const unsigned long long src_skip = (unsigned long long)b_first * img_bytes;
+    const unsigned long long src_left = g.src_total_bytes > src_skip ? g.src_total_bytes - src_skip : 0ull;
+    const __amdgpu_buffer_rsrc_t src_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.src) + src_skip, (unsigned)(src_left < 0xfffffff0ull ? src_left : 0xfffffff0ull));
+    const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt_planes, g.wt_bytes);     // 2 planes of N*K fp16
+    const unsigned OOB = 0xffffffffu;
+    const float sa = f16x2_scale(g.src_amax);
+    unsigned a_base[PA];
+    int a_h[PA], a_w[PA];
+    bool a_ok[PA];
+    int a_lds[PA];
+    const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int row = p * 32 + lrow;
+        const int i = mt_local * BM + row;
+        int b, hd, wd;
+        if (!classed) {
+            a_ok[p] = i < g.M;
+            const int ii = a_ok[p] ? i : 0;
+            b = ii / (g.Hd * g.Wd);
+            const int rem = ii - b * (g.Hd * g.Wd);
+            hd = rem / g.Wd; wd = rem - hd * g.Wd;
+        } else {
+            const int hc = g.cls_h[ph], wc = g.cls_w[pw];
+            a_ok[p] = i < g.B * hc * wc;
+            const int ii = a_ok[p] ? i : 0;
+            b = ii / (hc * wc);
+            const int rem = ii - b * (hc * wc);
+            const int hh = rem / wc;
+            hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
+        }
+        if (kc == 0) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
+        a_base[p] = (unsigned)(b - b_first) * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
+        if (!TRANSPOSED) { a_h[p] = hd * g.stride - g.pad; a_w[p] = wd * g.stride - g.pad; }
+        else { a_h[p] = hd + g.pad; a_w[p] = wd + g.pad; }
+        a_lds[p] = row * ROWB + (((kc >> 1) ^ lds_swz<MS>(row)) << 4) + ((kc & 1) << 3);
+    }
+    unsigned b_off[NB];
+    int b_lds[NB];
+    const unsigned plane_bytes = (unsigned)g.N * (unsigned)g.K * 2u;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int slot = tid + 256 * i;
+        const int row = slot >> 2, ch = slot & 3;
+        const bool ok = row < BN && (n0 + row) < g.N;
+        b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 2u + ch * 16u : OOB;
+        b_lds[i] = row < BN ? row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
+    }
+
+    f32x4 ra[PA];
+    u32x4 rb[NB][2];
+    const int CC = g.Cs / BK;
+    int r = r0, q = q0, cc = 0;
+    unsigned a_off[PA];
+    auto tap_setup = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int hi, wi;
+            bool ok = a_ok[p];
+            if (!TRANSPOSED) {
+                hi = a_h[p] + r; wi = a_w[p] + q;
+                ok = ok && (unsigned)hi < (unsigned)g.Hs && (unsigned)wi < (unsigned)g.Ws;
+            } else {
+                const int th = a_h[p] - r, tw = a_w[p] - q;
+                hi = th; wi = tw;
+                if (g.stride == 2) { hi = th >> 1; wi = tw >> 1; }
+                ok = ok && th >= 0 && tw >= 0 && hi < g.Hs && wi < g.Ws;
+            }
+            a_off[p] = ok ? a_base[p] + (unsigned)(hi * g.Ws + wi) * pix_bytes : OOB;
+        }
+    };
+    tap_setup();
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
+        const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 2u);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)(koff + pl * plane_bytes), 0);
+        if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } tap_setup(); }
+    };
+    int st_cc = 0;
+    auto store_tile = [&](int buf) {
+        unsigned char* as = smem_b + buf * STAGE;
+        unsigned char* bs = as + 2 * BM * ROWB;
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            f32x4 v = ra[p];
+            if (TRANSPOSED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
+            }
+            u32x2 hi, lo;
+            split2x4(v, sa, hi, lo);
+            *reinterpret_cast<u32x2*>(as + a_lds[p]) = hi;
+            *reinterpret_cast<u32x2*>(as + BM * ROWB + a_lds[p]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (b_lds[i] >= 0) {
+                *reinterpret_cast<u32x4*>(bs + b_lds[i]) = rb[i][0];
+                *reinterpret_cast<u32x4*>(bs + BN * ROWB + b_lds[i]) = rb[i][1];
+            }
+        if (++st_cc == CC) st_cc = 0;
+    };
+
+    accv acc0[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+
+    // fragment addressing: lane -> (row inside an MS-row tile, 16-B chunk of the 32-deep K-tile)
+    const int fr = lane & (MS - 1);                        // row of the MFMA tile
+    const int fq = lane / MS;                              // 32x32x16: k half (0/1); 16x16x32: k quarter (0..3)
+    const int fsw = lds_swz<MS>(fr);
+    const int a_row = (wm * WTM + fr) * ROWB, b_row = 2 * BM * ROWB + (wn * WTN + fr) * ROWB;
+
+    auto compute = [&](int buf) {
+        const unsigned char* base = smem_b + buf * STAGE;
+        if constexpr (MS == 32) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((2 * ks + fq) ^ fsw) << 4;
+                f16x8 fa[TM][2], fb[TN][2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const f16x8*>(base + pl * BM * ROWB + a_row + i * 32 * ROWB + co);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        fb[j][pl] = *reinterpret_cast<const f16x8*>(base + pl * BN * ROWB + b_row + j * 32 * ROWB + co);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[j][0], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][1], acc1[i][j], 0, 0, 0);
+                        acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[j][0], acc0[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
+            const int co = (fq ^ fsw) << 4;
+            f16x8 fb[TN][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fb[j][pl] = *reinterpret_cast<const f16x8*>(base + pl * BN * ROWB + b_row + j * 16 * ROWB + co);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f16x8 fa[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fa[pl] = *reinterpret_cast<const f16x8*>(base + pl * BM * ROWB + a_row + i * 16 * ROWB + co);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[j][0], acc1[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][1], acc1[i][j], 0, 0, 0);
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][0], acc0[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    const int KT = nr * nq * CC;
+    load_tile();
+    store_tile(0);
+    if (KT > 1) load_tile();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) store_tile((kt + 1) & 1);         // split + write the prefetched tile into the other stage
+        if (kt + 2 < KT) load_tile();                      // its successor's loads fly under this tile's MFMAs
+        compute(kt & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: c = (acc0 + 2^-11 acc1) / (s_A s_B); element (row, col) of a tile:
+    //   32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);   16x16: col = lane & 15, row = 4 (lane >> 4) + e
+    const float un = f16x2_unscale(g.src_amax) * f16x2_unscale(g.wt_amax);
+    const float un1 = un * (1.0f / 2048.0f);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * MS + fr;
+        const bool nok = n < g.N;
+        const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
+        const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) {
+                const int rl = MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e;
+                const float raw = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                acc0[i][j][e] = raw;                       // kept for the BN statistics below
+                const int m = row_m[wm * WTM + i * MS + rl];
+                if (nok && m >= 0) {
+                    float v = raw * sc + sh;
+                    v = y4_act(v, g.act);
+                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    g.dst[(long long)m * g.ldd + n] = v;
+                }
+            }
+        }
+    }
+    if (!TRANSPOSED && g.stats) {
+        float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the K loop ended with a barrier
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < ACCN; ++e) { const float v = acc0[i][j][e]; cs += v; css += v * v; }
+            if constexpr (MS == 16) {
+                cs += __shfl_xor(cs, 16, 64);
+                css += __shfl_xor(css, 16, 64);
+            }
+            cs += __shfl_xor(cs, 32, 64);
+            css += __shfl_xor(css, 32, 64);
+            if (fq == 0) {
+                const int c = wn * WTN + j * MS + fr;
+                red[(wm * BN + c) * 2 + 0] = cs;
+                red[(wm * BN + c) * 2 + 1] = css;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
+            const int n = n0 + c;
+            if (n < g.N) {
+                g.stats[((long long)mt_local * 2 + 0) * g.N + n] = cs;
+                g.stats[((long long)mt_local * 2 + 1) * g.N + n] = css;
+            }
+        }
+    }
+}
+
+// ==================================================================================== wgrad
+// D[n][j] = sum_p dy[p][n] * xg[p][j]; both operands transposed into LDS as [n or j][32 pixels] rows while being
+// split: each thread owns one 4-pixel x 4-channel block of each operand per 32-pixel chunk (4 coalesced 16-B loads,
+// a 4x4 register transpose folded into the fp16 packing, 8 ds_write_b64).
+template <int TN_, int TJ_, int MS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
+    constexpr int WTN = TN_ / 2, WTJ = TJ_ / 2;
+    constexpr int MI = WTN / MS, MJ = WTJ / MS;
+    constexpr int ACCN = MS == 32 ? 16 : 4;
+    constexpr int NBLK_A = 8 * (TN_ / 4), NBLK_B = 8 * (TJ_ / 4);     // 4x4 blocks per chunk (<= 256)
+    constexpr int STAGE = 2 * (TN_ + TJ_) * ROWB;
+    typedef float accv __attribute__((ext_vector_type(ACCN)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles = g.ntn * g.ntj;
+    int bid = y4_xcd_remap(blockIdx.x, tiles * g.splits);
+    const int split = bid / tiles;
+    bid -= split * tiles;
+    const int tn = bid / g.ntj, tj = bid - tn * g.ntj;
+    const int n0 = tn * TN_, j0 = tj * TJ_;
+
+    const int pg = tid & 7, cg = tid >> 3;               // pixel group (4 px), channel group (4 ch)
+    const bool a_act = tid < NBLK_A, b_act = tid < NBLK_B;
+    const int Cout4 = (g.Cout + 3) & ~3;
+    const bool an_ok = a_act && (n0 + cg * 4) < Cout4;
+    const int j = j0 + cg * 4;
+    const bool bj_ok = b_act && j < g.J;
+    int jr = 0, jq = 0, jc = 0;
+    if (bj_ok) { const int tap = j / g.Cin; jc = j - tap * g.Cin; jr = tap / g.k; jq = tap - jr * g.k; }
+
+    const int chunk0 = split * g.chunks_per_split;
+    int nchunks = (g.M + 31) / 32 - chunk0;
+    if (nchunks > g.chunks_per_split) nchunks = g.chunks_per_split;
+
+    const long long p_first = (long long)chunk0 * 32;
+    const int b_first = (int)(p_first / ((long long)g.Ho * g.Wo));
+    const unsigned long long x_skip = (unsigned long long)b_first * g.H * g.W * (unsigned long long)g.ldx * 4ull;
+    const unsigned long long dy_skip = (unsigned long long)p_first * (unsigned long long)g.lddy * 4ull;
+    const unsigned long long x_left = g.x_total_bytes > x_skip ? g.x_total_bytes - x_skip : 0ull;
+    const unsigned long long dy_left = g.dy_total_bytes > dy_skip ? g.dy_total_bytes - dy_skip : 0ull;
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.x) + x_skip, (unsigned)(x_left < 0xfffffff0ull ? x_left : 0xfffffff0ull));
+    const __amdgpu_buffer_rsrc_t dy_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.dy) + dy_skip, (unsigned)(dy_left < 0xfffffff0ull ? dy_left : 0xfffffff0ull));
+    const unsigned OOB = 0xffffffffu;
+    const float s_dy = f16x2_scale(g.dy_amax), s_x = f16x2_scale(g.x_amax);
+    int pb_b[4], pb_h[4], pb_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pix = chunk0 * 32 + pg * 4 + i;
+        const int pp = pix < g.M ? pix : (int)p_first;
+        const int bb = pp / (g.Ho * g.Wo);
+        pb_b[i] = bb - b_first;
+        const int rem = pp - bb * (g.Ho * g.Wo);
+        pb_h[i] = rem / g.Wo;
+        pb_w[i] = rem - pb_h[i] * g.Wo;
+    }
+    const unsigned a_off0 = an_ok ? (unsigned)(pg * 4) * (unsigned)g.lddy * 4u + (unsigned)(n0 + cg * 4) * 4u : OOB;
+    const unsigned dy_pix_bytes = (unsigned)g.lddy * 4u;
+    const unsigned chunk_bytes = 32u * dy_pix_bytes;
+    const unsigned x_pix_bytes = (unsigned)g.ldx * 4u;
+    // LDS byte offset of this thread's 8-B piece (4 pixels) inside row (cg*4 + e)
+    int w_lds[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int row = cg * 4 + e;
+        w_lds[e] = row * ROWB + (((pg >> 1) ^ lds_swz<MS>(row)) << 4) + ((pg & 1) << 3);
+    }
+
+    f32x4 ra[4], rb[4];
+    int ld_chunk = 0;
+    auto load_chunk = [&]() {
+        const int pbase = (chunk0 + ld_chunk) * 32 + pg * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = an_ok && pbase + i < g.M;
+            ra[i] = y4_buf_load4(dy_rsrc, ok ? a_off0 + (unsigned)i * dy_pix_bytes : OOB, (unsigned)ld_chunk * chunk_bytes);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hi = pb_h[i] * g.stride - g.pad + jr, wi = pb_w[i] * g.stride - g.pad + jq;
+            const bool ok = bj_ok && pbase + i < g.M && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            const unsigned off = (unsigned)((pb_b[i] * g.H + hi) * g.W + wi) * x_pix_bytes + (unsigned)jc * 4u;
+            rb[i] = y4_buf_load4(x_rsrc, ok ? off : OOB, 0u);
+            pb_w[i] += 32;
+            while (pb_w[i] >= g.Wo) { pb_w[i] -= g.Wo; if (++pb_h[i] == g.Ho) { pb_h[i] = 0; ++pb_b[i]; } }
+        }
+        ++ld_chunk;
+    };
+    // split 4 pixels x 4 channels and write the 4 channel rows (2 planes each) transposed
+    auto split_store = [&](const f32x4 (&v)[4], const float s, unsigned char* base, int rows) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 col = {v[0][e], v[1][e], v[2][e], v[3][e]};      // channel e of the 4 pixels
+            u32x2 hi, lo;
+            split2x4(col, s, hi, lo);
+            *reinterpret_cast<u32x2*>(base + w_lds[e]) = hi;
+            *reinterpret_cast<u32x2*>(base + rows * ROWB + w_lds[e]) = lo;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char* as = smem_b + buf * STAGE;
+        if (a_act) split_store(ra, s_dy, as, TN_);
+        if (b_act) split_store(rb, s_x, as + 2 * TN_ * ROWB, TJ_);
+    };
+
+    accv acc0[MI][MJ], acc1[MI][MJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jj = 0; jj < MJ; ++jj)
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) { acc0[i][jj][e] = 0.f; acc1[i][jj][e] = 0.f; }
+
+    const int fr = lane & (MS - 1), fq = lane / MS;
+    const int fsw = lds_swz<MS>(fr);
+    const int a_row = (wm * WTN + fr) * ROWB, b_row = 2 * TN_ * ROWB + (wn * WTJ + fr) * ROWB;
+    auto compute = [&](int buf) {
+        const unsigned char* base = smem_b + buf * STAGE;
+        if constexpr (MS == 32) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int co = ((2 * ks + fq) ^ fsw) << 4;
+                f16x8 fa[MI][2], fb[MJ][2];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const f16x8*>(base + pl * TN_ * ROWB + a_row + i * 32 * ROWB + co);
+#pragma unroll
+                for (int jj = 0; jj < MJ; ++jj)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        fb[jj][pl] = *reinterpret_cast<const f16x8*>(base + pl * TJ_ * ROWB + b_row + jj * 32 * ROWB + co);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < MJ; ++jj) {
+                        acc1[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][1], fb[jj][0], acc1[i][jj], 0, 0, 0);
+                        acc1[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[jj][1], acc1[i][jj], 0, 0, 0);
+                        acc0[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][0], fb[jj][0], acc0[i][jj], 0, 0, 0);
+                    }
+            }
+        } else {
+            const int co = (fq ^ fsw) << 4;
+            f16x8 fb[MJ][2];
+#pragma unroll
+            for (int jj = 0; jj < MJ; ++jj)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fb[jj][pl] = *reinterpret_cast<const f16x8*>(base + pl * TJ_ * ROWB + b_row + jj * 16 * ROWB + co);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                f16x8 fa[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fa[pl] = *reinterpret_cast<const f16x8*>(base + pl * TN_ * ROWB + a_row + i * 16 * ROWB + co);
+#pragma unroll
+                for (int jj = 0; jj < MJ; ++jj) {
+                    acc1[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[jj][0], acc1[i][jj], 0, 0, 0);
+                    acc1[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[jj][1], acc1[i][jj], 0, 0, 0);
+                    acc0[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[jj][0], acc0[i][jj], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+        if (nchunks > 1) load_chunk();
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+            if (ch + 2 < nchunks) load_chunk();
+            compute(ch & 1);
+            __syncthreads();
+        }
+    }
+    const float un = f16x2_unscale(g.dy_amax) * f16x2_unscale(g.x_amax);
+    const float un1 = un * (1.0f / 2048.0f);
+    float* out = g.out + (long long)split * g.Cout * g.J;
+#pragma unroll
+    for (int jj = 0; jj < MJ; ++jj) {
+        const int jcol = j0 + wn * WTJ + jj * MS + fr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int nb = n0 + wm * WTN + i * MS;
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) {
+                const int n = nb + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
+                if (n < g.Cout && jcol < g.J) out[(long long)n * g.J + jcol] = acc0[i][jj][e] * un + acc1[i][jj][e] * un1;
+            }
+        }
+    }
+}
+
+// ==================================================================================== filter planes, amax
+__global__ __launch_bounds__(256) void f16x2_split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                                 long long n, const unsigned* __restrict__ amax) {
+    const float s = f16x2_scale(amax);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        unsigned short hi, lo;
+        split2(w[i], s, hi, lo);
+        planes[i] = hi;
+        planes[n + i] = lo;
+    }
+}
+
+// [Cout][k][k][Cin] fp32 -> 2 fp16 planes of [Cin][k][k][Cout_pad] (dgrad filter)
+__global__ __launch_bounds__(256) void f16x2_transpose_split_filter_kernel(const float* __restrict__ w,
+                                                                           unsigned short* __restrict__ planes, int Cout, int Cin,
+                                                                           int kk, int Cout_pad, const unsigned* __restrict__ amax) {
+    const float s = f16x2_scale(amax);
+    const long long total = (long long)Cin * kk * Cout_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Cout_pad);
+        const long long t = i / Cout_pad;
+        const int tap = (int)(t % kk);
+        const int c = (int)(t / kk);
+        const float v = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
+        unsigned short hi, lo;
+        split2(v, s, hi, lo);
+        planes[i] = hi;
+        planes[total + i] = lo;
+    }
+}
+
+// max |finite element| over the first C channels of an NHWC tensor with pitch: bit pattern, folded with atomicMax
+// (order independent -> deterministic) into a word the caller has zeroed (or that already holds a lower bound)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long ld, long long M, int C,
+                                                   unsigned* __restrict__ out) {
+    unsigned m = 0u;
+    const int C4 = (C + 3) >> 2;
+    const long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / C4;
+        const int c = (int)(i - row * C4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + row * ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu;
+            if (c + e < C && b < 0x7f800000u && b > m) m = b;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ __launch_bounds__(256) void amax_strided_kernel(const float* __restrict__ x, long long ld, long long M, int C,
+                                                           unsigned* __restrict__ out) {
+    unsigned m = 0u;
+    const long long total = M * C;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / C;
+        const unsigned b = __float_as_uint(x[row * ld + (i - row * C)]) & 0x7fffffffu;
+        if (b < 0x7f800000u && b > m) m = b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+__global__ void amax_merge_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned v = *src; if (v) atomicMax(dst, v); }
+}
+
+int g_f16x2_shape = 32;          // MFMA shape of the f16x2 kernels: 32 (32x32x16) or 16 (16x16x32); Y4_F16X2_SHAPE overrides
+
+template <int BM, int BN, int WM, int WN, bool TR, int MS>
+int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
+    ConvGeom g = g0;
+    if (TR && g.stride == 2) {
+        int t = 0;
+        for (int c = 0; c < 4; ++c) {
+            const int ph = (3 - c) >> 1, pw = (3 - c) & 1;
+            g.cls_h[ph] = (g.Hd + 1 - ph) / 2;
+            g.cls_w[pw] = (g.Wd + 1 - pw) / 2;
+            g.cls_tile0[c] = t;
+            const long long n = (long long)g.B * g.cls_h[ph] * g.cls_w[pw];
+            t += (int)((n + BM - 1) / BM);
+        }
+        g.cls_tile0[4] = t;
+        g.mtiles = t;
+    } else {
+        g.cls_slot0[0] = 0;
+        g.mtiles = (g.M + BM - 1) / BM;
+    }
+    g.ntiles = (g.N + BN - 1) / BN;
+    {
+        const unsigned long long img = (unsigned long long)g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull;
+        const unsigned long long wb = (unsigned long long)g.N * g.K * 4ull;
+        const unsigned long long imgs_per_tile = (unsigned long long)BM / (unsigned long long)((g.Hd * g.Wd + 3) / 4 > 0 ? (g.Hd * g.Wd + 3) / 4 : 1) + 2;
+        if (img * imgs_per_tile >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+        g.src_total_bytes = (unsigned long long)g.B * img;
+        if (!g.wt_planes) return Y4_ERR_WORKSPACE;
+        g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
+    }
+    const size_t smem = 2ull * 2 * (BM + BN) * ROWB + BM * sizeof(int);
+    auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    int grid = g.mtiles * g.ntiles;
+    if (TR && g.stride == 2) {
+        int sl = 0;
+        for (int c = 0; c < 4; ++c) {
+            g.cls_slot0[c] = sl;
+            sl += ((g.cls_tile0[c + 1] - g.cls_tile0[c]) * g.ntiles + 7) / 8;
+        }
+        g.cls_slot0[4] = sl;
+        grid = sl * 8;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+template <bool TR, int MS>
+int dispatch_gather_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
+    if (nparts) *nparts = (g.M + 127) / 128;
+    if (g.N > 64) {
+        const long long nt = (g.N + 127) / 128;
+        const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
+        const double c128 = (double)((b128 + 511) / 512) * 128.0;
+        const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.10;
+        if (c64 < c128 && !(TR && g.stride == 2)) {
+            if (nparts) *nparts = (g.M + 63) / 64;
+            return launch_gather_f16x2<64, 128, 2, 2, TR, MS>(g, st);
+        }
+        return launch_gather_f16x2<128, 128, 2, 2, TR, MS>(g, st);
+    }
+    if (g.N > 32) return launch_gather_f16x2<128, 64, 2, 2, TR, MS>(g, st);
+    return launch_gather_f16x2<128, 32, 4, 1, TR, MS>(g, st);
+}
+
+template <int TN_, int TJ_, int MS>
+int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
+    const size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;
+    auto kern = conv_wgrad_f16x2<TN_, TJ_, MS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int f16x2_shape() {
+    static int s = -1;
+    if (s < 0) {
+        const char* e = getenv("Y4_F16X2_SHAPE");
+        s = e ? atoi(e) : g_f16x2_shape;
+        if (s != 16 && s != 32) s = g_f16x2_shape;
+    }
+    return s;
+}
+
+}  // namespace
+
+namespace y4 {
+
+int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts) {
+    if (f16x2_shape() == 16)
+        return transposed ? dispatch_gather_f16x2<true, 16>(g, st, nparts) : dispatch_gather_f16x2<false, 16>(g, st, nparts);
+    return transposed ? dispatch_gather_f16x2<true, 32>(g, st, nparts) : dispatch_gather_f16x2<false, 32>(g, st, nparts);
+}
+
+int f16x2_wgrad(const WgradGeom& g, hipStream_t st) {
+    if (f16x2_shape() == 16) {
+        if (g.tn == 128 && g.tj == 128) return launch_wgrad_f16x2<128, 128, 16>(g, st);
+        if (g.tn == 128) return launch_wgrad_f16x2<128, 64, 16>(g, st);
+        if (g.tj == 128) return launch_wgrad_f16x2<64, 128, 16>(g, st);
+        return launch_wgrad_f16x2<64, 64, 16>(g, st);
+    }
+    if (g.tn == 128 && g.tj == 128) return launch_wgrad_f16x2<128, 128, 32>(g, st);
+    if (g.tn == 128) return launch_wgrad_f16x2<128, 64, 32>(g, st);
+    if (g.tj == 128) return launch_wgrad_f16x2<64, 128, 32>(g, st);
+    return launch_wgrad_f16x2<64, 64, 32>(g, st);
+}
+
+int f16x2_split_filter(const float* w, unsigned short* planes, long long n, const unsigned* amax, hipStream_t st) {
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(f16x2_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w, planes, n, amax);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int f16x2_transpose_split_filter(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
+                                 const unsigned* amax, hipStream_t st) {
+    const long long total = (long long)Cin * kk * Cout_pad;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(f16x2_transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w, planes, Cout, Cin, kk, Cout_pad,
+                       amax);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st) {
+    if (hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st) != hipSuccess) return Y4_ERR_LAUNCH;
+    if (M <= 0 || C <= 0) return Y4_OK;
+    // 16-B loads when every row starts on a 16-B boundary and a row's last vector stays inside its pitch
+    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ((C + 3) & ~3) <= ld) {
+        const long long total = M * ((C + 3) / 4);
+        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, ld, M, C, amax_bits);
+    } else {
+        const long long total = M * C;
+        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        hipLaunchKernelGGL(amax_strided_kernel, dim3(blocks), dim3(256), 0, st, x, ld, M, C, amax_bits);
+    }
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st) {
+    hipLaunchKernelGGL(amax_merge_kernel, dim3(1), dim3(64), 0, st, dst, src);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+}  // namespace y4

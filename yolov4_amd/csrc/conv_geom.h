@@ -1,0 +1,59 @@
+// Problem descriptors shared by the implicit-GEMM convolution kernels (conv_igemm.hip: fp32-MFMA, bf16x3, bf16;
+// conv_f16x2.hip: the two-piece fp16 split).
+#pragma once
+#include "common.h"
+
+namespace y4 {
+
+struct ConvGeom {
+    // gathered ("source") tensor and produced ("dest") tensor, both NHWC with pitch
+    const float* src; const float* wt; float* dst;
+    const float* scale; const float* shift; const float* res;
+    float* stats;                 // forward only, optional: per-M-tile column sums [mtiles][2][N] of the raw output
+    long long lds_, ldd, ldr;     // pixel pitches (elements)
+    int B, Hs, Ws, Cs;            // source dims (Cs = GEMM-K channels, multiple of 32)
+    int Cs_valid;                 // channels >= Cs_valid of the source are treated as zero (pad lanes)
+    int Hd, Wd, N;                // dest spatial dims, N = dest channels (any)
+    int k, stride, pad;
+    int M;                        // B*Hd*Wd
+    int K;                        // k*k*Cs
+    int act;
+    int mtiles, ntiles;
+    // stride-2 dgrad: dest pixels are tiled per parity class (h&1, w&1) so that every row of a
+    // tile sees the SAME set of contributing filter taps (1, 2, 2 or 4 of the 9) and the K loop
+    // visits only those -- no zero-filled MFMAs.  cls_tile0[c] = first M-tile of class c.
+    int cls_tile0[5];
+    int cls_h[2], cls_w[2];       // class extents: (Hd + 1 - ph) / 2, (Wd + 1 - pw) / 2
+    int cls_slot0[5];             // classed launch: per-XCD slot ranges (each XCD gets 1/8 of EVERY class)
+    unsigned long long src_total_bytes;   // whole source tensor; each block re-bases its 32-bit buffer window at its first image
+    unsigned wt_bytes;            // filter extent for the buffer descriptor (< 4 GiB, checked on the host)
+    const unsigned short* wt_planes;   // split modes: filter pre-split into 16-bit planes [NP][N][K] (library scratch)
+    // f16x2 mode: device words holding the bit pattern of max|finite element| of the gathered tensor / the filter
+    // (NULL: operand taken unscaled); every element is multiplied by the power of two that brings that maximum
+    // into [2^14, 2^15) before it is split into fp16 pieces, and the epilogue undoes both scales
+    const unsigned* src_amax; const unsigned* wt_amax;
+};
+
+struct WgradGeom {
+    const float* x; const float* dy; float* out;    // out: dw (splits==1) or slab base
+    long long ldx, lddy;
+    int B, H, W, Cin, Ho, Wo, Cout;
+    int k, stride, pad;
+    int M;          // B*Ho*Wo
+    int J;          // k*k*Cin
+    int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
+    int tn, tj;     // tile edges chosen by the planner (64 or 128)
+    const unsigned* x_amax; const unsigned* dy_amax;   // f16x2 mode, as ConvGeom::src_amax
+    unsigned long long x_total_bytes, dy_total_bytes;   // whole tensors; blocks re-base their 32-bit windows
+};
+
+// conv_f16x2.hip
+int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts);
+int f16x2_wgrad(const WgradGeom& g, hipStream_t st);
+int f16x2_split_filter(const float* w, unsigned short* planes, long long n, const unsigned* amax, hipStream_t st);
+int f16x2_transpose_split_filter(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
+                                 const unsigned* amax, hipStream_t st);
+int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st);   // zeroes the word first
+int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st);
+
+}  // namespace y4

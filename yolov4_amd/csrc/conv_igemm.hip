@@ -12,36 +12,15 @@
 // groups), double buffered, register-staged global loads issued one K-tile ahead.
 #include <stdlib.h>
 #include "common.h"
+#include "conv_geom.h"
 
 namespace {
 
 constexpr int BK = 32;            // K-tile depth (floats)
 
 
-struct ConvGeom {
-    // gathered ("source") tensor and produced ("dest") tensor, both NHWC with pitch
-    const float* src; const float* wt; float* dst;
-    const float* scale; const float* shift; const float* res;
-    float* stats;                 // forward only, optional: per-M-tile column sums [mtiles][2][N] of the raw output
-    long long lds_, ldd, ldr;     // pixel pitches (elements)
-    int B, Hs, Ws, Cs;            // source dims (Cs = GEMM-K channels, multiple of 32)
-    int Cs_valid;                 // channels >= Cs_valid of the source are treated as zero (pad lanes)
-    int Hd, Wd, N;                // dest spatial dims, N = dest channels (any)
-    int k, stride, pad;
-    int M;                        // B*Hd*Wd
-    int K;                        // k*k*Cs
-    int act;
-    int mtiles, ntiles;
-    // stride-2 dgrad: dest pixels are tiled per parity class (h&1, w&1) so that every row of a
-    // tile sees the SAME set of contributing filter taps (1, 2, 2 or 4 of the 9) and the K loop
-    // visits only those -- no zero-filled MFMAs.  cls_tile0[c] = first M-tile of class c.
-    int cls_tile0[5];
-    int cls_h[2], cls_w[2];       // class extents: (Hd + 1 - ph) / 2, (Wd + 1 - pw) / 2
-    int cls_slot0[5];             // classed launch: per-XCD slot ranges (each XCD gets 1/8 of EVERY class)
-    unsigned long long src_total_bytes;   // whole source tensor; each block re-bases its 32-bit buffer window at its first image
-    unsigned wt_bytes;            // filter extent for the buffer descriptor (< 4 GiB, checked on the host)
-    const unsigned short* wt_planes;   // bf16x3 mode: filter pre-split into 3 bf16 planes [3][N][K] (library scratch)
-};
+using y4::ConvGeom;
+using y4::WgradGeom;
 
 // TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
 // TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
@@ -730,6 +709,7 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
 
 int g_conv_mode = 1;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs; default),
                               // 2: plain bf16 operands (RN), fp32 accumulate -- mixed precision, BASELINE config 5
+                              // 3: split-fp16 x2 (fp32-grade, 3 fp16 MFMAs, per-tensor power-of-two scale; conv_f16x2.hip)
 
 // ---------------------------------------------------------------- streaming 1x1 kernel (small K, small N)
 // The 1x1 layers on the 304^2 / 152^2 maps are HBM-bound (K, N <= 128: < 64 flop per byte); the tile machinery
@@ -991,17 +971,6 @@ int dispatch_gather(const ConvGeom& g, hipStream_t st, int* nparts = nullptr) {
 }
 
 // ------------------------------------------------------------------------------------ wgrad
-struct WgradGeom {
-    const float* x; const float* dy; float* out;    // out: dw (splits==1) or slab base
-    long long ldx, lddy;
-    int B, H, W, Cin, Ho, Wo, Cout;
-    int k, stride, pad;
-    int M;          // B*Ho*Wo
-    int J;          // k*k*Cin
-    int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
-    int tn, tj;     // tile edges chosen by the planner (64 or 128)
-    unsigned long long x_total_bytes, dy_total_bytes;   // whole tensors; blocks re-base their 32-bit windows
-};
 
 // D[n][j] = sum_p dy[p][n] * xg[p][j].  Block tile TN_ x TJ_ (64 or 128 each), 4 waves as 2x2,
 // K-chunks of 32 pixels, both operands kept pixel-major in LDS exactly as they lie in memory
@@ -1752,7 +1721,7 @@ constexpr int STEM_WAVES = 4096;
 extern "C" {
 
 int y4_set_conv_mode(int mode) {
-    if (mode < 0 || mode > 2) return Y4_ERR_SHAPE;
+    if (mode < 0 || mode > 3) return Y4_ERR_SHAPE;
     g_conv_mode = mode;
     return Y4_OK;
 }
@@ -1765,10 +1734,14 @@ int y4_set_workspace(void* ptr, size_t bytes) {
     return Y4_OK;
 }
 
+// scratch arena layout: 256 bytes of amax words (f16x2 mode: [0] filter, [1] gathered tensor when the caller gave none),
+// then the filter planes
+constexpr size_t SCRATCH_HDR = 256;
+
 static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
                          const float* scale, const float* shift, int act,
-                         const float* residual, int ldr, float* stats, int* nparts, void* stream) {
+                         const float* residual, int ldr, float* stats, int* nparts, const unsigned* x_amax, void* stream) {
     if (!x || !w || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1788,13 +1761,27 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
     g.M = (int)M; g.K = k * k * Cin; g.act = act;
     if (g_conv_mode != 0) {
         const long long nw = (long long)Cout * g.K;
-        if (!g_scratch || g_scratch_bytes < (size_t)nw * 6) return Y4_ERR_WORKSPACE;   // y4_set_workspace() first
-        unsigned short* planes = static_cast<unsigned short*>(g_scratch);
+        if (!g_scratch || g_scratch_bytes < SCRATCH_HDR + (size_t)nw * 6) return Y4_ERR_WORKSPACE;   // y4_set_workspace() first
+        unsigned* hdr = static_cast<unsigned*>(g_scratch);
+        unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(g_scratch) + SCRATCH_HDR);
+        g.wt_planes = planes;
+        if (g_conv_mode == 3) {
+            int rc = y4::amax_launch(w, g.K, Cout, g.K, hdr, y4_stream(stream));
+            if (rc != Y4_OK) return rc;
+            rc = y4::f16x2_split_filter(w, planes, nw, hdr, y4_stream(stream));
+            if (rc != Y4_OK) return rc;
+            if (!x_amax) {                                  // no producer-side maximum: one extra pass over the input
+                rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, hdr + 1, y4_stream(stream));
+                if (rc != Y4_OK) return rc;
+                x_amax = hdr + 1;
+            }
+            g.src_amax = x_amax; g.wt_amax = hdr;
+            return y4::f16x2_gather(g, false, y4_stream(stream), nparts);
+        }
         const int blocks = (int)((nw + 255) / 256 > 4096 ? 4096 : (nw + 255) / 256);
         hipLaunchKernelGGL(split_filter_kernel, dim3(blocks), dim3(256), 0, y4_stream(stream), w, planes, nw,
                            g_conv_mode == 2 ? 1 : 3);
         Y4_CHECK_LAUNCH();
-        g.wt_planes = planes;
     }
     return dispatch_gather<false>(g, y4_stream(stream), nparts);
 }
@@ -1802,9 +1789,20 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
 int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                       int B, int H, int W, int Cin, int Cout, int k, int stride,
                       const float* scale, const float* shift, int act,
-                      const float* residual, int ldr, void* stream) {
+                      const float* residual, int ldr, const unsigned* x_amax, void* stream) {
     return conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, scale, shift, act, residual, ldr, nullptr,
-                         nullptr, stream);
+                         nullptr, x_amax, stream);
+}
+
+int y4_amax_f32(const float* x, int ldx, long long M, int C, unsigned* amax_bits, void* stream) {
+    if (!x || !amax_bits) return Y4_ERR_NULL;
+    if (M < 0 || C <= 0 || ldx < C) return Y4_ERR_SHAPE;
+    return y4::amax_launch(x, ldx, M, C, amax_bits, y4_stream(stream));
+}
+
+int y4_amax_merge_u32(unsigned* dst, const unsigned* src, void* stream) {
+    if (!dst || !src) return Y4_ERR_NULL;
+    return y4::amax_merge(dst, src, y4_stream(stream));
 }
 
 size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
@@ -1817,12 +1815,13 @@ size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k
 
 int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                               int B, int H, int W, int Cin, int Cout, int k, int stride,
-                              float* partials, size_t partial_bytes, long long* nparts_host, void* stream) {
+                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
+                              void* stream) {
     if (!partials || !nparts_host) return Y4_ERR_NULL;
     if (partial_bytes < y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;
     int np = 0;
     const int rc = conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, nullptr, nullptr, Y4_ACT_LINEAR,
-                                 nullptr, 0, partials, &np, stream);
+                                 nullptr, 0, partials, &np, x_amax, stream);
     if (rc != Y4_OK) return rc;
     *nparts_host = np;
     return Y4_OK;
@@ -1830,12 +1829,14 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
 
 size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
     const size_t cp = (size_t)((Cout + 31) / 32) * 32;
-    return (size_t)Cin * k * k * cp * 6;       // fp32 transposed filter (4 B) or 3 bf16 planes (6 B) per element
+    // fp32 transposed filter (4 B), 3 bf16 planes (6 B) or 2 fp16 planes (4 B) per element, + 64 B of amax words
+    return (size_t)Cin * k * k * cp * 6 + 64;
 }
 
 static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx, int lddx,
                            int B, int H, int W, int Cin, int Cout, int k, int stride,
-                           void* workspace, size_t workspace_bytes, void* stream) {
+                           void* workspace, size_t workspace_bytes, const unsigned* dy_amax, const float* residual, int ldr,
+                           void* stream) {
     if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1848,7 +1849,13 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     float* wt = static_cast<float*>(workspace);
     const long long total = (long long)Cin * k * k * Cout_pad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    if (g_conv_mode != 0)
+    unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)total * 6);
+    if (g_conv_mode == 3) {
+        int rc = y4::amax_launch(w, (long long)k * k * Cin, Cout, k * k * Cin, hdr, st);
+        if (rc != Y4_OK) return rc;
+        rc = y4::f16x2_transpose_split_filter(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad, hdr, st);
+        if (rc != Y4_OK) return rc;
+    } else if (g_conv_mode != 0)
         hipLaunchKernelGGL(transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w,
                            static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad, g_conv_mode == 2 ? 1 : 3);
     else
@@ -1856,9 +1863,10 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     Y4_CHECK_LAUNCH();
     const int pad = (k - 1) / 2;
     ConvGeom g{};
-    g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = nullptr;
+    if (residual && ldr < Cin) return Y4_ERR_SHAPE;
+    g.src = dy; g.wt = wt; g.dst = dx; g.scale = nullptr; g.shift = nullptr; g.res = residual;
     g.wt_planes = static_cast<const unsigned short*>(workspace);
-    g.lds_ = lddy; g.ldd = lddx; g.ldr = 0;
+    g.lds_ = lddy; g.ldd = lddx; g.ldr = ldr;
     g.B = B;
     g.Hs = (H + 2 * pad - k) / stride + 1;
     g.Ws = (W + 2 * pad - k) / stride + 1;
@@ -1867,24 +1875,38 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     const long long M = (long long)B * H * W;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cout_pad; g.act = Y4_ACT_LINEAR;
+    if (g_conv_mode == 3) {
+        if (!dy_amax) {
+            // pad channels of dy may hold anything: the maximum is taken over the valid channels only
+            const int rc = y4::amax_launch(dy, lddy, (long long)B * g.Hs * g.Ws, Cout, hdr + 1, st);
+            if (rc != Y4_OK) return rc;
+            dy_amax = hdr + 1;
+        }
+        g.src_amax = dy_amax; g.wt_amax = hdr;
+        return y4::f16x2_gather(g, true, st, nullptr);
+    }
     return dispatch_gather<true>(g, st);
 }
 
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
-                        void* workspace, size_t workspace_bytes, void* stream) {
-    return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, stream);
+                        void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
+                        const float* residual, int ldr, void* stream) {
+    return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, dy_amax,
+                           residual, ldr, stream);
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
     WgradGeom g{};
     wgrad_plan(B, H, W, Cin, Cout, k, stride, g);
-    return g.splits > 1 ? (size_t)g.splits * Cout * g.J * sizeof(float) : 16;
+    // slabs of the split-K partial sums + 64 B of amax words (f16x2 mode)
+    return (g.splits > 1 ? (size_t)g.splits * Cout * g.J * sizeof(float) : 0) + 64;
 }
 
 int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
+                        void* stream) {
     if (!x || !dy || !dw) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1902,15 +1924,33 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
         if (range_px * per_px >= 0xfffffff0ull) return Y4_ERR_SHAPE;      // pitch more than 2x the channel count at > 4 GiB
     }
     hipStream_t st = y4_stream(stream);
+    const size_t slab_bytes = g.splits > 1 ? (size_t)g.splits * Cout * g.J * sizeof(float) : 0;
     if (g.splits > 1) {
         if (!workspace) return Y4_ERR_NULL;
-        if (workspace_bytes < (size_t)g.splits * Cout * g.J * sizeof(float)) return Y4_ERR_WORKSPACE;
+        if (workspace_bytes < slab_bytes) return Y4_ERR_WORKSPACE;
         g.out = static_cast<float*>(workspace);
     } else {
         g.out = dw;
     }
     int rc;
-    if (g_conv_mode == 1) {
+    if (g_conv_mode == 3) {
+        if (!x_amax || !dy_amax) {
+            if (!workspace || workspace_bytes < slab_bytes + 64) return Y4_ERR_WORKSPACE;
+            unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + slab_bytes);
+            if (!x_amax) {
+                rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, hdr, st);
+                if (rc != Y4_OK) return rc;
+                x_amax = hdr;
+            }
+            if (!dy_amax) {
+                rc = y4::amax_launch(dy, lddy, (long long)B * g.Ho * g.Wo, Cout, hdr + 1, st);
+                if (rc != Y4_OK) return rc;
+                dy_amax = hdr + 1;
+            }
+        }
+        g.x_amax = x_amax; g.dy_amax = dy_amax;
+        rc = y4::f16x2_wgrad(g, st);
+    } else if (g_conv_mode == 1) {
         if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, 3>(g, st);
         else if (g.tn == 128) rc = launch_wgrad<128, 64, 3>(g, st);
         else if (g.tj == 128) rc = launch_wgrad<64, 128, 3>(g, st);
@@ -1959,7 +1999,7 @@ int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long lo
     const long long blocks = (g.M + 255) / 256;
     if (blocks >= (1ll << 31)) return Y4_ERR_SHAPE;
     // matrix-core variant: bf16x3 arithmetic, 32-bit byte offsets into x (non-negative strides)
-    const bool mfma_ok = g_conv_mode == 1 && sxb >= 0 && sxc >= 0 && sxh >= 0 && sxw >= 0 &&
+    const bool mfma_ok = (g_conv_mode == 1 || g_conv_mode == 3) && sxb >= 0 && sxc >= 0 && sxh >= 0 && sxw >= 0 &&
                          ((long long)(B - 1) * sxb + 2 * sxc + (long long)(H - 1) * sxh + (long long)(W - 1) * sxw + 1) * 4 < 0xfffffff0ll &&
                          (long long)H * W < (1 << 24);
     if (mfma_ok) {

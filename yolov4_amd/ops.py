@@ -121,7 +121,7 @@ def conv_out_hw(H, W, k, s):
 
 
 # ------------------------------------------------------------------ raw op wrappers (no autograd)
-def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1):
+def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None):
     L = lib()
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -143,11 +143,11 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
     check(L.y4_conv2d_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, B, H, W, Cin, Cout, k, s,
-                              _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _stream()), 'conv2d_fwd')
+                              _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _ptr(x_amax), _stream()), 'conv2d_fwd')
     return out
 
 
-def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, eps):
+def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, eps, x_amax=None):
     """Training-mode conv: raw output y + BatchNorm batch statistics taken in the conv epilogue
     (per-M-tile column sums, folded in fp64 by a second-stage kernel).  Returns (y, mean, invstd)."""
     L = lib()
@@ -171,7 +171,7 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
         x, ldx = as_nhwc(x)
         n = ctypes.c_longlong(0)
         check(L.y4_conv2d_fwd_bnstats_f32(_ptr(x), ldx, _ptr(w), _ptr(y), ldy, B, H, W, Cin, Cout, k, s,
-                                          _ptr(part), pbytes, ctypes.byref(n), _stream()), 'conv2d_fwd_bnstats')
+                                          _ptr(part), pbytes, ctypes.byref(n), _ptr(x_amax), _stream()), 'conv2d_fwd_bnstats')
         nparts = n.value
     mean = torch.empty(Cout, device=x.device, dtype=torch.float32)
     invstd = torch.empty(Cout, device=x.device, dtype=torch.float32)
@@ -183,7 +183,7 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     return y, mean, invstd
 
 
-def conv_dgrad_raw(dy, w, x_shape, k, s):
+def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None):
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
@@ -192,8 +192,11 @@ def conv_dgrad_raw(dy, w, x_shape, k, s):
     dx = empty_nhwc(B, Cin, H, W, dy.device)
     nbytes = L.y4_conv2d_dgrad_workspace(Cin, Cout, k)
     ws = _ws(nbytes, dy.device)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = as_nhwc(residual, need_vec4=False)
     check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
-                                _ptr(ws), nbytes, _stream()), 'conv2d_dgrad')
+                                _ptr(ws), nbytes, _ptr(dy_amax), _ptr(residual), ldr, _stream()), 'conv2d_dgrad')
     return dx
 
 
@@ -209,7 +212,7 @@ def _is_krsc_dense(t):
 WGRAD_STATS = {'in_place': 0, 'temporary': 0}      # filter gradients written into a caller slot vs a temporary
 
 
-def conv_wgrad_raw(x, dy, w_shape, k, s, out=None):
+def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None):
     """out: optional fp32 tensor of shape w_shape whose memory is dense KRSC (e.g. a gradient slot of a flat
     DDP bucket): the kernel then writes the filter gradient in place."""
     L = lib()
@@ -235,7 +238,7 @@ def conv_wgrad_raw(x, dy, w_shape, k, s, out=None):
     nbytes = L.y4_conv2d_wgrad_workspace(B, H, W, Cin, Cout, k, s)
     ws = _ws(nbytes, dy.device)
     check(L.y4_conv2d_wgrad_f32(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, H, W, Cin, Cout, k, s,
-                                _ptr(ws), nbytes, _stream()), 'conv2d_wgrad')
+                                _ptr(ws), nbytes, _ptr(x_amax), _ptr(dy_amax), _stream()), 'conv2d_wgrad')
     return dw
 
 
