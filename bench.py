@@ -2,8 +2,8 @@
 # -*- coding: utf-8 -*-
 """Headline benchmark (BASELINE.json): images/sec of one YOLOv4 training step
 (forward + YOLOLoss + backward, no optimizer) at 608x608, batch 64 per GPU,
-synthetic inputs per SURVEY.md §8(d) config 3, fp32-grade conv arithmetic (bf16x3 by default, --conv-mode f32 for
-the fp32 MFMA).
+synthetic inputs per SURVEY.md §8(d) config 3, fp32-grade conv arithmetic (f16x2 by default; --conv-mode bf16x3 / f32
+for the 3-piece bf16 split / the fp32 MFMA).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -49,9 +49,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--no-kernel-events', action='store_true')
-    ap.add_argument('--conv-mode', default='bf16x3', choices=['bf16x3', 'f32', 'bf16'],
-                    help='conv arithmetic: exact 3-way bf16 split on the bf16 matrix cores (fp32-grade, default) '
-                         'or the fp32 MFMA fma chain')
+    ap.add_argument('--conv-mode', default='f16x2', choices=['f16x2', 'bf16x3', 'f32', 'bf16'],
+                    help='conv arithmetic: 2-piece fp16 split (fp32-grade, 3 MFMAs per product, default), exact 3-way bf16 '
+                         'split (6 MFMAs), the fp32 MFMA fma chain, or plain bf16 operands (mixed precision)')
     ap.add_argument('--conv-table', default=None, help='write a per-shape conv timing table to this file')
     return ap.parse_args()
 
@@ -97,10 +97,10 @@ class ConvTimer:
         def f_wgrad(x, dy, w_shape, k, s, *a, **kw):
             B, Cout, Ho, Wo = dy.shape
             mode = args_conv_mode()
-            kern = 'conv_wgrad_mfma_f32' if mode == 'f32' else 'conv_wgrad_bf16x3'
+            kern = {'f32': 'conv_wgrad_mfma_f32', 'f16x2': 'conv_wgrad_f16x2'}.get(mode, 'conv_wgrad_bf16x3')
             tn, tj = (64 if Cout <= 64 else 128), (64 if k * k * x.shape[1] <= 64 else 128)
-            timer.sym = 'conv_stem_wgrad_kernel' if x.shape[1] == 3 else \
-                f'{kern}<{tn}, {tj}' + ('>' if mode == 'f32' else (', 1>' if mode == 'bf16' else ', 3>'))
+            tail = {'f32': '>', 'bf16': ', 1>', 'bf16x3': ', 3>', 'f16x2': f", {os.environ.get('Y4_F16X2_SHAPE', '32')}>"}[mode]
+            timer.sym = 'conv_stem_wgrad_kernel' if x.shape[1] == 3 else f'{kern}<{tn}, {tj}' + tail
             return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k, (x.shape[1], Cout, k, s, x.shape[2])
 
         ops.conv_fwd_raw = bracket(ops.conv_fwd_raw, 'conv_fwd', f_fwd)
@@ -147,8 +147,25 @@ def gather_symbol(transposed, M, N, Cs, Cs_valid, k, stride, ld):
     Cs = channels of the gathered tensor (padded), ld = its pixel pitch."""
     mode = args_conv_mode()
     if Cs == 3:
-        return 'conv_stem_fwd_bf16x3_kernel' if mode == 'bf16x3' else 'conv_stem_fwd_kernel'
+        return 'conv_stem_fwd_bf16x3_kernel' if mode in ('bf16x3', 'f16x2') else 'conv_stem_fwd_kernel'
     tr = 'true' if transposed else 'false'
+    if mode == 'f16x2':
+        ms = int(os.environ.get('Y4_F16X2_SHAPE', '32'))
+        if (k == 1 and stride == 1 and Cs in (32, 64, 128) and Cs_valid == Cs and N <= 128 and M * ld * 4 < 0xfffffff0
+                and M >= 128 * 1024):
+            nt = (N + 31) // 32
+            nt = 4 if nt >= 3 else nt
+            return f'conv1x1_stream_f16x2<{Cs // 16}, {nt}, {8 if (Cs == 128 and nt == 4) else 4}>'
+        if N > 64:
+            nt = (N + 127) // 128
+            b128, b64 = (M + 127) // 128 * nt, (M + 63) // 64 * nt
+            c128 = ((b128 + 511) // 512) * 128.0
+            c64 = ((b64 + 511) // 512) * 64.0 * 1.10
+            bm = 64 if (c64 < c128 and not (transposed and stride == 2)) else 128
+            return f'conv_gather_f16x2<{bm}, 128, 2, 2, {tr}, {ms}>'
+        if N > 32:
+            return f'conv_gather_f16x2<128, 64, 2, 2, {tr}, {ms}>'
+        return f'conv_gather_f16x2<128, 32, 4, 1, {tr}, {ms}>'
     if (mode == 'bf16x3' and k == 1 and stride == 1 and Cs in (32, 64, 128) and Cs_valid == Cs and N <= 128
             and Cs * ((N + 31) // 32 * 32) <= (16384 if Cs == 128 else 8192) and M * ld * 4 < 0xfffffff0 and M >= 128 * 1024):
         nt = (N + 31) // 32
@@ -174,52 +191,46 @@ def gather_symbol(transposed, M, N, Cs, Cs_valid, k, stride, ld):
     return name(128, 32, 4, 1)
 
 
-def pmc_traffic_symbol(sym):
-    """HBM-side bytes per launch for one kernel symbol from the recorded rocprofv3 --pmc passes (see pmc_traffic)."""
-    for name in ('r01_pmc_hbm_traffic_per_kernel_v8.json', 'r01_pmc_hbm_traffic_per_kernel.json'):
-        path = os.path.join(ROOT, 'profiles', name)
-        if os.path.isfile(path):
+MODES = {
+    'f16x2': {'kk': 'f16x2', 'mfmas': 3, 'peak': PEAK_BF16_MFMA_TFLOPS, 'instr': 'v_mfma_f32_32x32x16_f16 / 16x16x32_f16',
+              'peak_note': 'dense fp16 MFMA peak 2500 / 3 MFMAs per fp32-grade product',
+              'text': 'f16x2: fp32 operands scaled by a per-tensor power of two and split into 2 fp16 pieces (11 + 11 bits), '
+                      '3 fp16 MFMAs per product, two fp32 accumulators (per-product error ~2^-22: rms 4.3e-7 of the output at '
+                      'K = 4608 vs 1.19e-6 for an fp32 fma chain, tests/test_gpu_parity.py::test_conv_modes_accuracy_vs_fp64)'},
+    'bf16x3': {'kk': 'bf16x3', 'mfmas': 6, 'peak': PEAK_BF16_MFMA_TFLOPS, 'instr': 'v_mfma_f32_32x32x16_bf16',
+               'peak_note': 'dense bf16 MFMA peak 2500 / 6 MFMAs per fp32-exact product',
+               'text': 'bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate '
+                       '(error <= the fp32-MFMA fma chain, see DESIGN.md)'},
+    'bf16': {'kk': 'bf16x3', 'mfmas': 1, 'peak': PEAK_BF16_MFMA_TFLOPS, 'instr': 'v_mfma_f32_32x32x16_bf16',
+             'peak_note': 'dense bf16 MFMA peak',
+             'text': 'plain bf16 MFMA operands (RN), fp32 accumulate; fp32 BN/loss/NMS (config 5, mixed precision)'},
+    'f32': {'kk': 'mfma_f32', 'mfmas': 1, 'peak': PEAK_F32_MFMA_TFLOPS, 'instr': 'v_mfma_f32_32x32x2_f32',
+            'peak_note': 'dense fp32 MFMA peak', 'text': 'fp32 MFMA fma chain (v_mfma_f32_32x32x2_f32)'},
+}
+
+
+def pmc_recorded(kind, sym):
+    """(value, source file) for one kernel symbol from the newest committed rocprofv3 --pmc recording of this command
+    under profiles/ (kind 'hbm_traffic': bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes;
+    kind 'mfma_util': SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x elapsed cycles)).  Recorded, not live."""
+    import glob
+    key = {'hbm_traffic': 'hbm_bytes_per_launch_corrected', 'mfma_util': 'mfma_util'}[kind]
+    pat = {'hbm_traffic': 'r*_pmc_hbm_traffic_per_kernel*.json', 'mfma_util': 'r*_pmc_mfma_util_per_kernel*.json'}[kind]
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', pat)), reverse=True):
+        try:
             for k, v in json.load(open(path)).items():
-                if sym in k:
-                    return v['hbm_bytes_per_launch_corrected']
-    return None
-
-
-def pmc_mfma_util(sym):
-    """Cycle-based matrix-pipe utilisation of one kernel symbol from the recorded rocprofv3 --pmc pass of this command
-    (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x elapsed cycles), profiles/r01_pmc_mfma_util_per_kernel_v10.json)."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_mfma_util_per_kernel_v10.json')
-    if os.path.isfile(path):
-        for k, v in json.load(open(path)).items():
-            if sym in k:
-                return v['mfma_util']
-    return None
-
-
-def pmc_traffic(kind):
-    """HBM-side bytes per launch of the kernel family (largest tile variant), from the separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/, corrected as
-    MI355X_MICROARCH.md prescribes: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes).  PMC counters cannot
-    be read from inside the process, so this is the recorded measurement or None."""
-    fam = {'conv_fwd': ('conv_gather_', '<128, 128, 2, 2, false'), 'conv_dgrad': ('conv_gather_', '<128, 128, 2, 2, true'),
-           'conv_wgrad': ('conv_wgrad_', '<128, 128')}[kind]
-    mode = 'mfma_f32' if args_conv_mode() == 'f32' else 'bf16x3'
-    # newest recording first (v8: bf16x3 kernels of this round's final code; the first file holds the fp32-MFMA kernels)
-    for name in ('r01_pmc_hbm_traffic_per_kernel_v8.json', 'r01_pmc_hbm_traffic_per_kernel.json'):
-        path = os.path.join(ROOT, 'profiles', name)
-        if not os.path.isfile(path):
+                if sym in k and key in v:
+                    return v[key], os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
             continue
-        for k, v in json.load(open(path)).items():
-            if fam[0] + mode in k and fam[1] in k:
-                return v['hbm_bytes_per_launch_corrected']
-    return None
+    return None, None
 
 
 _ARGS = {}
 
 
 def args_conv_mode():
-    return _ARGS.get('conv_mode', 'bf16x3')
+    return _ARGS.get('conv_mode', 'f16x2')
 
 
 def cpu_baseline(size, batch):
@@ -303,8 +314,7 @@ def main():
     def step():
         ddp.zero_grad()
         loss = crit(ddp(x), {'padded_labels': labels})
-        loss.backward()
-        ddp.finish_backward()
+        loss.backward()                                  # the exchange is waited for by BucketedDDP's end-of-backward callback
         return loss
 
     for _ in range(args.warmup):
@@ -342,11 +352,7 @@ def main():
             'config': {'workload': f'configs[2]: 1xMI355X training step, {S}x{S} bs={B}/GPU, fwd+bwd+YOLOLoss HIP kernels, '
                                    f'synthetic targets (SURVEY 8d config 3); random-init weights',
                        'global_batch': world * B, 'img_size': S, 'parallelism': f'dp{world}',
-                       'conv_arithmetic': ('bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, '
-                                           'fp32 accumulate (error <= the fp32-MFMA fma chain, see DESIGN.md)'
-                                           if args.conv_mode == 'bf16x3' else
-                                           'plain bf16 MFMA operands (RN), fp32 accumulate; fp32 BN/loss/NMS (config 5, mixed precision)'
-                                           if args.conv_mode == 'bf16' else 'fp32 MFMA fma chain (v_mfma_f32_32x32x2_f32)'),
+                       'conv_arithmetic': MODES[args.conv_mode]['text'],
                        'peak_hbm_gib': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
                        'loss': lossv, 'conv_tflops_whole_step': value / world * flop_img / 1e12},
         }
@@ -357,40 +363,38 @@ def main():
             fam_of = {'conv_wgrad': 'conv_wgrad', 'conv_stem_wgrad': 'conv_wgrad'}
             dom = next((f for p_, f in fam_of.items() if dsym.startswith(p_)), None) or \
                 ('conv_dgrad' if ', true' in dsym else 'conv_fwd')
-            kk = 'mfma_f32' if args.conv_mode == 'f32' else 'bf16x3'
-            kname = {'conv_fwd': f'conv_gather_{kk}<..,false> (forward implicit GEMM; filter split, BN-stat fold kernels included)',
-                     'conv_dgrad': f'conv_gather_{kk}<..,true> (dgrad implicit GEMM; filter transpose/split included)',
-                     'conv_wgrad': f'conv_wgrad_{kk} (+ slab reduce)'}[dom]
-            # The roofline of the instruction stream that actually runs: bf16x3 spends 6 dense bf16 MFMAs per fp32-exact
-            # product, so its ceiling in ALGORITHMIC flop/s is the bf16 MFMA peak / 6 (= 416.7 TFLOP/s); frac is then the
-            # matrix-pipe utilisation at nominal clock.  (Against the fp32 MFMA peak of 157.3 the same number exceeds 1.)
-            peak = {'bf16': PEAK_BF16_MFMA_TFLOPS, 'bf16x3': PEAK_BF16_MFMA_TFLOPS / 6.0, 'f32': PEAK_F32_MFMA_TFLOPS}[args.conv_mode]
-            fam = summ[dom]
-            summ = dict(summ)
-            summ[dom] = dict(fam, tflops=syms[dsym]['tflops'], seconds=syms[dsym]['seconds'], launches=syms[dsym]['launches'])
-            out['roofline'] = {'bound': 'mfma', 'achieved': summ[dom]['tflops'], 'peak': peak,
-                               'unit': 'TFLOP/s', 'frac': summ[dom]['tflops'] / peak,
-                               'traffic': pmc_traffic_symbol(dsym),
-                               'mfma_util_pmc': pmc_mfma_util(dsym),
+            mi = MODES[args.conv_mode]
+            kname = {'conv_fwd': f"conv_gather_{mi['kk']}<..,false> (forward implicit GEMM; filter split, BN-stat fold kernels included)",
+                     'conv_dgrad': f"conv_gather_{mi['kk']}<..,true> (dgrad implicit GEMM; filter transpose/split included)",
+                     'conv_wgrad': f"conv_wgrad_{mi['kk']} (+ slab reduce)"}[dom]
+            # The roofline of the instruction stream that actually runs: a split mode spends `mfmas` dense 16-bit MFMAs per
+            # fp32-grade product, so its ceiling in ALGORITHMIC flop/s is the 16-bit MFMA peak / mfmas; frac is then the
+            # matrix-pipe utilisation at nominal clock (identical to executed flop/s over the 2.5 PFLOP/s dense peak).
+            peak = mi['peak'] / mi['mfmas']
+            tf = syms[dsym]['tflops']
+            traffic, traffic_src = pmc_recorded('hbm_traffic', dsym)
+            util, util_src = pmc_recorded('mfma_util', dsym)
+            out['roofline'] = {'bound': 'mfma', 'achieved': tf, 'peak': peak, 'unit': 'TFLOP/s', 'frac': tf / peak,
+                               'traffic': traffic,
                                'kernel': dsym,
-                               'peak_note': {'bf16x3': 'dense bf16 MFMA peak 2500 / 6 MFMAs per fp32-exact product',
-                                             'bf16': 'dense bf16 MFMA peak', 'f32': 'dense fp32 MFMA peak'}[args.conv_mode],
-                               'vs_fp32_mfma_peak': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS,
+                               'measured': 'achieved / frac / avg_launch_ms / per_symbol: LIVE in this run (HIP events on the launch '
+                                           'stream around every conv launch of the timed steps)',
+                               'recorded': {'note': 'PMC counters cannot be read from inside the process: traffic and mfma_util_pmc are '
+                                                    'RECORDED values of separate rocprofv3 --pmc passes of this same command, not '
+                                                    'measurements of this run; null when no recording of this kernel symbol exists',
+                                            'traffic_source': traffic_src, 'mfma_util_pmc': util, 'mfma_util_source': util_src},
+                               'peak_note': mi['peak_note'],
+                               'frac_of_dense_16bit_peak_algorithmic': tf / PEAK_BF16_MFMA_TFLOPS,
+                               'vs_fp32_mfma_peak': tf / PEAK_F32_MFMA_TFLOPS,
                                'kernel_note': 'dominant kernel symbol by total time inside the timed steps; the HIP-event bracket '
                                               'around each launch also covers its filter split / slab-reduce / BN-stat fold '
                                               'helpers (a few % of the duration); family: ' + kname,
-                               'mfma_pipe': ({'instr': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': 6 * summ[dom]['tflops'],
-                                              'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': 6 * summ[dom]['tflops'] / PEAK_BF16_MFMA_TFLOPS}
-                                             if args.conv_mode == 'bf16x3' else
-                                             {'instr': 'v_mfma_f32_32x32x16_bf16', 'executed_tflops': summ[dom]['tflops'],
-                                              'peak': PEAK_BF16_MFMA_TFLOPS, 'frac': summ[dom]['tflops'] / PEAK_BF16_MFMA_TFLOPS}
-                                             if args.conv_mode == 'bf16' else
-                                             {'instr': 'v_mfma_f32_32x32x2_f32', 'executed_tflops': summ[dom]['tflops'],
-                                              'peak': PEAK_F32_MFMA_TFLOPS, 'frac': summ[dom]['tflops'] / PEAK_F32_MFMA_TFLOPS}),
-                               'avg_launch_ms': summ[dom]['seconds'] / summ[dom]['launches'] * 1e3,
-                               'launches': summ[dom]['launches'],
+                               'mfma_pipe': {'instr': mi['instr'], 'executed_tflops': mi['mfmas'] * tf, 'peak': mi['peak'],
+                                             'frac': mi['mfmas'] * tf / mi['peak']},
+                               'avg_launch_ms': syms[dsym]['seconds'] / syms[dsym]['launches'] * 1e3,
+                               'launches': syms[dsym]['launches'],
                                'all_conv_kernels': {k: {'tflops': round(v['tflops'], 2), 'ms_per_step': round(v['seconds'] / args.steps * 1e3, 2)}
-                                                    for k, v in timer.summary().items()},
+                                                    for k, v in summ.items()},
                                'per_symbol': {k: {'tflops': round(v['tflops'], 2), 'avg_launch_ms': round(v['seconds'] / v['launches'] * 1e3, 4),
                                                   'launches': v['launches']}
                                               for k, v in sorted(syms.items(), key=lambda kv: -kv[1]['seconds'])}}

@@ -90,7 +90,8 @@ int y4_set_workspace(void* ptr, size_t bytes);
 int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                       int B, int H, int W, int Cin, int Cout, int k, int stride,
                       const float* scale, const float* shift, int act,
-                      const float* residual, int ldr, const unsigned* x_amax /* mode 3, nullable */, void* stream);
+                      const float* residual, int ldr, const unsigned* x_amax /* mode 3, nullable */,
+                      unsigned* y_amax /* mode 3, nullable: max|finite y| folded in with atomicMax */, void* stream);
 /* max |finite element| over the first C channels of an NHWC tensor (pitch ldx), as a bit pattern (mode 3 operand
  * maximum).  y4_amax_f32 overwrites *amax_bits; y4_amax_merge_u32 folds *src into *dst (a concat buffer's maximum is
  * the maximum of its parts).  Integer atomicMax: order independent. */
@@ -161,17 +162,20 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
                                 float* mean, float* invstd, float* running_mean, float* running_var,
                                 long long* num_batches_tracked, float momentum, float eps,
                                 void* workspace, size_t workspace_bytes, void* stream);
-/* z = act(gamma*(y-mean)*invstd + beta) + residual   (residual may be NULL) */
+/* z = act(gamma*(y-mean)*invstd + beta) + residual   (residual may be NULL).
+ * out_amax (nullable, device word): max|finite z| is folded into it with atomicMax (the caller zeroes it, or it
+ * already holds the maximum of other parts of the same concat buffer) -- the operand maximum of conv mode 3. */
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, void* stream);
+                      long long M, int C, unsigned* out_amax, void* stream);
 /* Backward of the two ops above wrt y, gamma, beta given dz (grad wrt z; the residual branch
  * receives dz itself).  dy may alias dz.  workspace: y4_bn_workspace(M, C) bytes. */
 int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,
-                      long long M, int C, void* workspace, size_t workspace_bytes, void* stream);
+                      long long M, int C, void* workspace, size_t workspace_bytes,
+                      unsigned* out_amax /* nullable: max|finite dy|, as above */, void* stream);
 /* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249). workspace: C doubles */
 int y4_bias_grad_f32(const float* dy, int lddy, long long M, int C, float* dbias,
                      void* workspace, size_t workspace_bytes, void* stream);

@@ -55,11 +55,11 @@ def test_workspace_queries_run_on_host():
 
 def test_null_and_shape_errors_are_reported_before_any_launch():
     L = yolov4_amd.lib()
-    assert L.y4_conv2d_fwd_f32(None, 32, None, None, 32, 1, 8, 8, 32, 32, 3, 1, None, None, 0, None, 0, None, None) == 2
+    assert L.y4_conv2d_fwd_f32(None, 32, None, None, 32, 1, 8, 8, 32, 32, 3, 1, None, None, 0, None, 0, None, None, None) == 2
     # Cin not a multiple of 32 -> shape error (pointers are fake but never dereferenced on the host)
     fake = 0x1000
-    assert L.y4_conv2d_fwd_f32(fake, 48, fake, fake, 32, 1, 8, 8, 48, 32, 3, 1, None, None, 0, None, 0, None, None) == 1
-    assert L.y4_conv2d_fwd_f32(fake, 32, fake, fake, 32, 1, 8, 8, 32, 32, 5, 1, None, None, 0, None, 0, None, None) == 1
+    assert L.y4_conv2d_fwd_f32(fake, 48, fake, fake, 32, 1, 8, 8, 48, 32, 3, 1, None, None, 0, None, 0, None, None, None) == 1
+    assert L.y4_conv2d_fwd_f32(fake, 32, fake, fake, 32, 1, 8, 8, 32, 32, 5, 1, None, None, 0, None, 0, None, None, None) == 1
 
 
 def test_state_dict_matches_reference_tree():

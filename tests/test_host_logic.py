@@ -26,11 +26,11 @@ def test_convbnact_ctx_does_not_hold_its_output(monkeypatch):
     from yolov4_amd import ops
     from yolov4_amd.darknet.darknet import ConvBNAct
 
-    def fake_bnstats(x, w, k, s, rm, rv, nbt, mom, eps):
+    def fake_bnstats(x, w, k, s, rm, rv, nbt, mom, eps, x_amax=None):
         y = torch.nn.functional.conv2d(x, w, None, s, (k - 1) // 2)
         return y, y.mean((0, 2, 3)), (y.var((0, 2, 3), unbiased=False) + eps).rsqrt()
 
-    def fake_bn_act(y, mean, invstd, gamma, beta, act, residual=None, out=None):
+    def fake_bn_act(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None):
         z = (y - mean.view(1, -1, 1, 1)) * (invstd * gamma).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
         if out is not None:
             out.copy_(z)
@@ -105,6 +105,58 @@ def test_ddp_heals_slots_after_optimizer_zero_grad_and_finishes_by_itself():
     for a, b in zip(net.parameters(), ref.parameters()):
         torch.testing.assert_close(a.grad, b.grad)
     assert net[0].weight.grad.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_ddp_counts_in_place_gradients_once():
+    """A kernel that writes a gradient straight into its bucket slot reports it by hand and hands autograd None; torch
+    still fires the leaf's post-accumulate hook.  Counting both would launch a bucket's exchange before its other
+    gradients exist (round 1 did)."""
+    from yolov4_amd.ddp import BucketedDDP
+
+    class InPlaceMul(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, holder):
+            ctx.save_for_backward(x, w)
+            ctx.holder = holder
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            p = ctx.holder['p']
+            launched_before = [b.launched for b in ctx.holder['ddp'].buckets]
+            ctx.holder['log'].append(launched_before)
+            if getattr(p, '_y4_grad_fresh', False):
+                p._y4_grad_fresh = False
+                p.grad.copy_((g * x).sum(0))
+                p._y4_grad_ready()
+                return g * w, None, None
+            return g * w, (g * x).sum(0), None
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w1 = torch.nn.Parameter(torch.ones(4))
+            self.w2 = torch.nn.Parameter(torch.full((4,), 2.0))
+            self.box = {}
+
+        def forward(self, x):
+            h = InPlaceMul.apply(x, self.w1, dict(self.box, p=self.w1))
+            return InPlaceMul.apply(h, self.w2, dict(self.box, p=self.w2))
+
+    net = Net().train()
+    ddp = BucketedDDP(net, bucket_mb=1.0)            # both parameters in ONE bucket
+    assert len(ddp.buckets) == 1
+    net.box.update(ddp=ddp, log=[])
+    x = torch.randn(3, 4)
+    for step in range(2):
+        ddp.zero_grad()
+        ddp(x).sum().backward()
+        assert ddp.buckets[0].pending == 0 and ddp.buckets[0].launched
+        # when the SECOND gradient of the bucket was being produced the bucket had not been launched yet
+        assert net.box['log'][-1] == [False]
+    torch.testing.assert_close(net.w2.grad, x.sum(0))
+    torch.testing.assert_close(net.w1.grad, 2 * x.sum(0))
 
 
 def test_fused_optimizer_zero_grad_keeps_ddp_slots():

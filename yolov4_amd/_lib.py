@@ -30,7 +30,7 @@ PROTOTYPES = {
     'y4_set_conv_mode': (I, [I]),
     'y4_get_conv_mode': (I, []),
     'y4_set_workspace': (I, [P, Z]),
-    'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P]),
+    'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P, P]),
     'y4_amax_f32': (I, [P, I, L, I, P, P]),
     'y4_amax_merge_u32': (I, [P, P, P]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
@@ -46,8 +46,8 @@ PROTOTYPES = {
     'y4_bn_finalize_workspace': (Z, [I]),
     'y4_bn_finalize_partials_f32': (I, [P, L, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_stats_f32': (I, [P, I, L, I, P, P, P, P, P, F, F, P, Z, P]),
-    'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P]),
-    'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P]),
+    'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, P]),
+    'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P]),
     'y4_bias_grad_f32': (I, [P, I, L, I, P, P, Z, P]),
     'y4_bn_fold_f32': (I, [P, P, P, P, F, P, P, I, P]),
     'y4_copy_channels_f32': (I, [P, I, P, I, L, I, P]),

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     //   32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);   16x16: col = lane & 15, row = 4 (lane >> 4) + e
     const float un = f16x2_unscale(g.src_amax) * f16x2_unscale(g.wt_amax);
     const float un1 = un * (1.0f / 2048.0f);
+    unsigned out_max = 0u;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WTN + j * MS + fr;
@@ -335,9 +336,19 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     v = y4_act(v, g.act);
                     if (g.res) v += g.res[(long long)m * g.ldr + n];
                     g.dst[(long long)m * g.ldd + n] = v;
+                    const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
+                    if (vb < 0x7f800000u && vb > out_max) out_max = vb;
                 }
             }
         }
+    }
+    if (!TRANSPOSED && g.dst_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)out_max, off, 64);
+            out_max = o > out_max ? o : out_max;
+        }
+        if (lane == 0 && out_max) atomicMax(g.dst_amax, out_max);
     }
     if (!TRANSPOSED && g.stats) {
         float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the K loop ended with a barrier
@@ -573,6 +584,216 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     }
 }
 
+// ==================================================================================== streaming 1x1 (small K, small N)
+// The 1x1 layers on the 304^2 / 152^2 / 76^2 maps with K, N <= 128 are HBM-bound; the whole filter (2 fp16 planes)
+// stays in LDS for the life of a persistent block and every wave streams its own 32 pixel rows from global memory
+// straight into the MFMA A-operand layout (lane = pixel, 8 consecutive channels = 32 contiguous bytes), splits them
+// in registers and never meets a barrier; the next tile's loads fly under this tile's MFMAs / stores.
+template <int KS, int NT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2(const ConvGeom g) {
+    constexpr int NTHR = NW * 64, TROWS = NW * 32;
+    constexpr int K = KS * 16;
+    constexpr int PITCH = K * 2 + 16;                    // LDS row pitch: conflict-free ds_read_b128 for K = 32/64/128
+    constexpr int N32 = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    {
+        constexpr int CPR = K / 8;                       // 16-B chunks per filter row
+        const unsigned char* wp = reinterpret_cast<const unsigned char*>(g.wt_planes);
+        for (int i = tid; i < 2 * N32 * CPR; i += NTHR) {
+            const int pl = i / (N32 * CPR);
+            const int rem = i - pl * (N32 * CPR);
+            const int row = rem / CPR, ch = rem - row * CPR;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < g.N) v = *reinterpret_cast<const u32x4*>(wp + ((size_t)pl * g.N + row) * (K * 2) + ch * 16);
+            *reinterpret_cast<u32x4*>(smem_b + (pl * N32 + row) * PITCH + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src, (unsigned)g.src_total_bytes);   // < 4 GiB (host)
+    const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
+    const int mtiles = g.mtiles;
+    const float sa = f16x2_scale(g.src_amax);
+    const float un = f16x2_unscale(g.src_amax) * f16x2_unscale(g.wt_amax);
+    const float un1 = un * (1.0f / 2048.0f);
+    constexpr int KH = KS == 8 ? 4 : KS;
+    f32x4 ra0[KH][2], ra1[KH][2];
+    auto load = [&](f32x4 (&ra)[KH][2], int tile, int ks0) {
+        const int m = tile * TROWS + wave * 32 + fr;
+        const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 32u : 0xffffffffu;
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            ra[ks][0] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 64u);
+            ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 64u + 16u);
+        }
+    };
+    float cs[NT], css[NT];
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        cs[j] = 0.f; css[j] = 0.f;
+        const int n = j * 32 + fr;
+        sc[j] = (g.scale && n < g.N) ? g.scale[n] : 1.0f;
+        sh[j] = (g.shift && n < g.N) ? g.shift[n] : 0.0f;
+    }
+    const unsigned char* b_frag = smem_b + fr * PITCH + fh * 16;
+    f32x16 acc0[NT], acc1[NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { acc0[j][e] = 0.f; acc1[j][e] = 0.f; }
+    };
+    auto mma = [&](f32x4 (&ra)[KH][2], int ks0) {
+        if constexpr (KS == 8) asm volatile("" ::: "memory");      // re-read the filter fragments per tile (no spills)
+#pragma unroll
+        for (int ks = 0; ks < KH; ++ks) {
+            u32x2 h0, l0, h1, l1;
+            split2x4(ra[ks][0], sa, h0, l0);
+            split2x4(ra[ks][1], sa, h1, l1);
+            const u32x4 qh = {h0[0], h0[1], h1[0], h1[1]}, ql = {l0[0], l0[1], l1[0], l1[1]};
+            const f16x8 fah = __builtin_bit_cast(f16x8, qh), fal = __builtin_bit_cast(f16x8, ql);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const f16x8 fbh = *reinterpret_cast<const f16x8*>(b_frag + (j * 32) * PITCH + (ks0 + ks) * 32);
+                const f16x8 fbl = *reinterpret_cast<const f16x8*>(b_frag + (N32 + j * 32) * PITCH + (ks0 + ks) * 32);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fbh, acc1[j], 0, 0, 0);
+                acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbl, acc1[j], 0, 0, 0);
+                acc0[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc0[j], 0, 0, 0);
+            }
+        }
+    };
+    unsigned out_max = 0u;
+    auto epilogue = [&](int tile) {
+        const int mbase = tile * TROWS + wave * 32 + 4 * fh;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 32 + fr;
+            const bool nok = n < g.N;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float raw = acc0[j][e] * un + acc1[j][e] * un1;
+                cs[j] += raw; css[j] += raw * raw;           // rows past M are exact zeros
+                const int m = mbase + (e & 3) + 8 * (e >> 2);
+                if (nok && m < g.M) {
+                    float v = raw * sc[j] + sh[j];
+                    v = y4_act(v, g.act);
+                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    g.dst[(long long)m * g.ldd + n] = v;
+                    const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
+                    if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                }
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < mtiles) load(ra0, tile, 0);
+    if constexpr (KS == 8) {
+        while (tile < mtiles) {
+            load(ra1, tile, KH);
+            zero_acc();
+            mma(ra0, 0);
+            const int tn = tile + gridDim.x;
+            if (tn < mtiles) load(ra0, tn, 0);
+            mma(ra1, KH);
+            epilogue(tile);
+            tile = tn;
+        }
+    } else {
+        while (tile < mtiles) {
+            const int t1 = tile + gridDim.x;
+            if (t1 < mtiles) load(ra1, t1, 0);
+            zero_acc(); mma(ra0, 0); epilogue(tile);
+            if (t1 >= mtiles) break;
+            const int t2 = t1 + gridDim.x;
+            if (t2 < mtiles) load(ra0, t2, 0);
+            zero_acc(); mma(ra1, 0); epilogue(t1);
+            tile = t2;
+        }
+    }
+    if (g.dst_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)out_max, off, 64);
+            out_max = o > out_max ? o : out_max;
+        }
+        if (lane == 0 && out_max) atomicMax(g.dst_amax, out_max);
+    }
+    if (g.stats) {                                        // one partial row per block: [gridDim][2][N]
+        __syncthreads();                                  // every wave is done with the filter planes
+        float* red = reinterpret_cast<float*>(smem_b);    // [NW][N32][2]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = cs[j], b = css[j];
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (fh == 0) { red[(wave * N32 + j * 32 + fr) * 2] = a; red[(wave * N32 + j * 32 + fr) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        for (int c = tid; c < N32; c += NTHR) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { a += red[(w * N32 + c) * 2]; b += red[(w * N32 + c) * 2 + 1]; }
+            if (c < g.N) {
+                g.stats[((long long)blockIdx.x * 2 + 0) * g.N + c] = a;
+                g.stats[((long long)blockIdx.x * 2 + 1) * g.N + c] = b;
+            }
+        }
+    }
+}
+
+template <int KS, int NT, int NW = 4>
+int launch_stream1x1_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
+    ConvGeom g = g0;
+    g.mtiles = (g.M + NW * 32 - 1) / (NW * 32);
+    g.ntiles = 1;
+    g.src_total_bytes = (unsigned long long)g.M * (unsigned long long)g.lds_ * 4ull;
+    size_t smem = (size_t)2 * NT * 32 * (KS * 32 + 16);
+    const size_t red = (size_t)NW * NT * 32 * 2 * sizeof(float);
+    if (smem < red) smem = red;
+    auto kern = conv1x1_stream_f16x2<KS, NT, NW>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    const int resident = NW == 8 ? 256 : 512;             // blocks per CU: 1 (8 waves) or 2
+    const int grid = g.mtiles < resident ? g.mtiles : resident;
+    if (nparts) *nparts = grid;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+// eligibility: 1x1 stride 1, K in {32,64,128}, N <= 128, 32-bit addressable source, every source channel valid, and
+// enough rows to be worth a persistent launch
+bool stream1x1_f16x2_ok(const ConvGeom& g) {
+    if (g.k != 1 || g.stride != 1 || !g.wt_planes) return false;
+    if (g.Cs != 32 && g.Cs != 64 && g.Cs != 128) return false;
+    if (g.Cs_valid != g.Cs || g.N > 128) return false;
+    if ((unsigned long long)g.M * (unsigned long long)g.lds_ * 4ull >= 0xfffffff0ull) return false;
+    return g.M >= 128 * 1024;
+}
+
+int dispatch_stream1x1_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
+    const int nt = (g.N + 31) / 32;
+    switch (g.Cs / 16 * 10 + nt) {
+        case 21: return launch_stream1x1_f16x2<2, 1>(g, st, nparts);
+        case 22: return launch_stream1x1_f16x2<2, 2>(g, st, nparts);
+        case 23: case 24: return launch_stream1x1_f16x2<2, 4>(g, st, nparts);
+        case 41: return launch_stream1x1_f16x2<4, 1>(g, st, nparts);
+        case 42: return launch_stream1x1_f16x2<4, 2>(g, st, nparts);
+        case 43: case 44: return launch_stream1x1_f16x2<4, 4>(g, st, nparts);
+        case 81: return launch_stream1x1_f16x2<8, 1>(g, st, nparts);
+        case 82: return launch_stream1x1_f16x2<8, 2>(g, st, nparts);
+        case 83: case 84: return launch_stream1x1_f16x2<8, 4, 8>(g, st, nparts);
+        default: return Y4_ERR_SHAPE;
+    }
+}
+
 // ==================================================================================== filter planes, amax
 __global__ __launch_bounds__(256) void f16x2_split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
                                                                  long long n, const unsigned* __restrict__ amax) {
@@ -751,6 +972,7 @@ int f16x2_shape() {
 namespace y4 {
 
 int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts) {
+    if (stream1x1_f16x2_ok(g)) return dispatch_stream1x1_f16x2(g, st, nparts);
     if (f16x2_shape() == 16)
         return transposed ? dispatch_gather_f16x2<true, 16>(g, st, nparts) : dispatch_gather_f16x2<false, 16>(g, st, nparts);
     return transposed ? dispatch_gather_f16x2<true, 32>(g, st, nparts) : dispatch_gather_f16x2<false, 32>(g, st, nparts);

@@ -32,6 +32,7 @@ struct ConvGeom {
     // (NULL: operand taken unscaled); every element is multiplied by the power of two that brings that maximum
     // into [2^14, 2^15) before it is split into fp16 pieces, and the epilogue undoes both scales
     const unsigned* src_amax; const unsigned* wt_amax;
+    unsigned* dst_amax;           // f16x2 forward, optional: max|finite output| folded in with atomicMax
 };
 
 struct WgradGeom {

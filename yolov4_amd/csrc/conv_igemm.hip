@@ -1741,7 +1741,8 @@ constexpr size_t SCRATCH_HDR = 256;
 static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
                          const float* scale, const float* shift, int act,
-                         const float* residual, int ldr, float* stats, int* nparts, const unsigned* x_amax, void* stream) {
+                         const float* residual, int ldr, float* stats, int* nparts, const unsigned* x_amax,
+                         unsigned* y_amax, void* stream) {
     if (!x || !w || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1775,7 +1776,7 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
                 if (rc != Y4_OK) return rc;
                 x_amax = hdr + 1;
             }
-            g.src_amax = x_amax; g.wt_amax = hdr;
+            g.src_amax = x_amax; g.wt_amax = hdr; g.dst_amax = y_amax;
             return y4::f16x2_gather(g, false, y4_stream(stream), nparts);
         }
         const int blocks = (int)((nw + 255) / 256 > 4096 ? 4096 : (nw + 255) / 256);
@@ -1789,9 +1790,9 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
 int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                       int B, int H, int W, int Cin, int Cout, int k, int stride,
                       const float* scale, const float* shift, int act,
-                      const float* residual, int ldr, const unsigned* x_amax, void* stream) {
+                      const float* residual, int ldr, const unsigned* x_amax, unsigned* y_amax, void* stream) {
     return conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, scale, shift, act, residual, ldr, nullptr,
-                         nullptr, x_amax, stream);
+                         nullptr, x_amax, y_amax, stream);
 }
 
 int y4_amax_f32(const float* x, int ldx, long long M, int C, unsigned* amax_bits, void* stream) {
@@ -1821,7 +1822,7 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
     if (partial_bytes < y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;
     int np = 0;
     const int rc = conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, nullptr, nullptr, Y4_ACT_LINEAR,
-                                 nullptr, 0, partials, &np, x_amax, stream);
+                                 nullptr, 0, partials, &np, x_amax, nullptr, stream);
     if (rc != Y4_OK) return rc;
     *nparts_host = np;
     return Y4_OK;

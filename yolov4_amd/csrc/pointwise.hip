@@ -158,14 +158,33 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     }
 }
 
+// optional by-product of the sweeps that PRODUCE a conv operand: bit pattern of max|finite output| folded into *out
+// with an integer atomicMax (order independent); conv mode 3 ("f16x2") scales its operands by it
+__device__ __forceinline__ void amax_track(unsigned& m, const f32x4 o) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned b = __float_as_uint(o[e]) & 0x7fffffffu;
+        if (b < 0x7f800000u && b > m) m = b;
+    }
+}
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned* out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // ---------------------------------------------------------------- BN apply + act (+ skip)
 __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const float* __restrict__ res, long long ldr, float* __restrict__ z, long long ldz,
-    long long M, int C, int tpr, int rpb) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax) {
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
+    unsigned amax = 0u;
     for (int c0 = cv * 4; c0 < C; c0 += tpr * 4) {
         f32x4 a, b;
 #pragma unroll
@@ -180,8 +199,10 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
             for (int e = 0; e < 4; ++e) o[e] = y4_act(v[e] * a[e] + b[e], act);
             if (res) o += ld4(res + m * ldr + c0);
             st4(z + m * ldz + c0, o);
+            amax_track(amax, o);
         }
     }
+    if (out_amax) amax_commit(amax, out_amax);
 }
 
 // backward pass 1: sum_g[c] = sum_m g, sum_gx[c] = sum_m g * xhat,  g = dz * act'(u)
@@ -278,10 +299,11 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const double* __restrict__ acc, float* __restrict__ dy, long long lddy,
-    long long M, int C, int tpr, int rpb) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax) {
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     const double invM = 1.0 / (double)M;
+    unsigned amax = 0u;
     for (int c0 = cv * 4; c0 < C; c0 += tpr * 4) {
         f32x4 mu, is, ga, be, k1, k2;
 #pragma unroll
@@ -301,8 +323,10 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
                 o[e] = ga[e] * is[e] * (g - k1[e] - xh * k2[e]);
             }
             st4(dy + m * lddy + c0, o);
+            amax_track(amax, o);
         }
     }
+    if (out_amax) amax_commit(amax, out_amax);
 }
 
 __global__ __launch_bounds__(PW_THREADS) void colsum_kernel(const float* __restrict__ x, long long ldx, long long M,
@@ -654,7 +678,7 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, void* stream) {
+                      long long M, int C, unsigned* out_amax, void* stream) {
     if (!y || !mean || !invstd || !gamma || !beta || !z) return Y4_ERR_NULL;
     if (!vec_ok(y, ldy, C) || !vec_ok(z, ldz, C) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
         return Y4_ERR_SHAPE;
@@ -663,7 +687,7 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
                        (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
-                       M, C, rm.tpr, rm.rpb);
+                       M, C, rm.tpr, rm.rpb, out_amax);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -671,7 +695,7 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
 int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,
-                      long long M, int C, void* workspace, size_t workspace_bytes, void* stream) {
+                      long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
@@ -692,7 +716,8 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
     long long blocks = (M + rm.rpb - 1) / rm.rpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
-                       (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb);
+                       (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,
+                       out_amax);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

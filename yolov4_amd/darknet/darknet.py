@@ -49,11 +49,15 @@ class ConvBNAct(nn.Module):
         self.stride = stride
         self.has_bn = bool(bn)
 
-    def forward(self, x, residual=None, out=None):
-        """out: optional destination (a CatBuffer slot) for the activation; the reference has no such argument."""
+    def forward(self, x, residual=None, out=None, dres_put=None, dres_take=None):
+        """out: optional destination (a CatBuffer slot) for the activation; dres_put / dres_take: the shared box through
+        which a ResBlock unit's 3x3 conv hands the skip gradient to its 1x1 conv (see ResBlock).  The reference has
+        none of these arguments."""
         n = self.norm
+        io = {}
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
-               'training': self.training}
+               'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
+               'dres_put': dres_put, 'dres_take': dres_take}
         if self.has_bn:
             use_batch_stats = self.training or n.running_mean is None
             cfg['training'] = use_batch_stats
@@ -74,7 +78,17 @@ class ConvBNAct(nn.Module):
             self.conv.weight.data = w.data.contiguous(memory_format=torch.channels_last)
             w = self.conv.weight
         cfg['weight_param'] = self.conv.weight       # its gradient may be produced on the side stream (ops._wgrad_to_param)
-        return ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
+        z = ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
+        return ops.tag_amax(z, io.get('z_amax'))
+
+
+def res_unit(pair, x):
+    """x + conv3x3(conv1x1(x)) (darknet.py:76-80): the skip is added in the 3x3's BN+act kernel; in backward the gradient
+    arriving over the skip is parked by the 3x3 and added in the 1x1's dgrad epilogue, so neither direction spends a
+    separate elementwise pass."""
+    xa, xb = ops.fork(x)
+    box = {} if (torch.is_grad_enabled() and xa.requires_grad and pair[0].training) else None
+    return pair[1](pair[0](xa, dres_take=box), residual=xb, dres_put=box)
 
 
 class ResBlock(nn.Module):
@@ -89,8 +103,7 @@ class ResBlock(nn.Module):
     def forward(self, x):
         for pair in self.module_list:
             if self.shortcut:
-                xa, xb = ops.fork(x)
-                x = pair[1](pair[0](xa), residual=xb)      # skip fused into the 3x3's epilogue
+                x = res_unit(pair, x)
             else:
                 x = pair[1](pair[0](x))
         return x
@@ -112,8 +125,7 @@ class CSPDownSample0(nn.Module):
         xa, xb = ops.fork(self.base(x))
         cb = ops.cat_buffer(xa, [self.part2_2.conv.out_channels, self.part1.conv.out_channels])
         x1 = self.part1(xa, out=cb.slot(1))
-        ta, tb = ops.fork(self.part2_1_1(xb))
-        x2 = self.part2_1_2[1](self.part2_1_2[0](ta), residual=tb)
+        x2 = res_unit(self.part2_1_2, self.part2_1_1(xb))
         x2 = self.part2_2(x2, out=cb.slot(0))
         return self.transition(ops.cat([x2, x1], into=cb))
 

@@ -28,11 +28,11 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ('flat', 'params', 'views', 'pending', 'work', 'launched')
+    __slots__ = ('flat', 'params', 'views', 'pending', 'work', 'launched', 'seen')
 
     def __init__(self, flat, params, views):
         self.flat, self.params, self.views = flat, params, views
-        self.pending, self.work, self.launched = 0, None, False
+        self.pending, self.work, self.launched, self.seen = 0, None, False, set()
 
 
 def _align(n, a):
@@ -121,6 +121,13 @@ class BucketedDDP(torch.nn.Module):
         index = {id(p): i for i, p in enumerate(bucket.params)}
 
         def hook(param):
+            # Once per parameter and backward.  A gradient written in place by a kernel is reported by hand
+            # (param._y4_grad_ready); the Function then returns None for that input and torch (2.10) STILL runs the
+            # post-accumulate hook of the leaf -- counted twice, a bucket would be exchanged before its last gradient
+            # has been written.
+            if id(param) in bucket.seen:
+                return
+            bucket.seen.add(id(param))
             if not self._in_backward:
                 self._begin_backward()
             # a gradient that does not live in its slot (p.grad was None or replaced after forward): move it in
@@ -211,6 +218,7 @@ class BucketedDDP(torch.nn.Module):
         micro-steps of an accumulation window (yolo/engine/build.py:56-69 steps every ACCUMULATION_STEPS)."""
         for b in self.buckets:
             b.pending, b.work, b.launched = len(b.params), None, False
+            b.seen.clear()
 
     def forward(self, *a, **kw):
         if torch.is_grad_enabled() and self.module.training:

@@ -115,13 +115,65 @@ def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
 
 
+# ------------------------------------------------------------------ operand maxima (conv mode 3, "f16x2")
+# The two-piece fp16 split scales every conv operand by a power of two taken from max|tensor| (include/yolov4_amd.h).
+# The maximum is a by-product of the kernel that PRODUCES the operand (BN+act forward, BN backward, conv epilogue):
+# a device word ("cell") that travels with the tensor as the Python attribute `y4_amax`.  Cells of tensors that share
+# a concat buffer are one shared cell (atomicMax).  A tensor without a cell is always legal: the consumer then spends
+# one extra pass over it (ops.amax_raw / inside the library).
+_AMAX = {'pool': {}, 'N': 4096}
+
+
+def f16x2_mode():
+    return lib().y4_get_conv_mode() == 3
+
+
+def new_amax(device):
+    """A zeroed device word out of a ring of 4096; each half is re-zeroed (one tiny fill) when the ring enters it, i.e.
+    >= 2048 allocations (several training steps) after its cells were handed out."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _AMAX['pool'].get(key)
+    if st is None:
+        st = {'buf': torch.zeros(_AMAX['N'], dtype=torch.int32, device=device), 'i': 0}
+        _AMAX['pool'][key] = st
+    i, half = st['i'], _AMAX['N'] // 2
+    if i % half == 0:
+        st['buf'][i:i + half].zero_()
+    st['i'] = (i + 1) % _AMAX['N']
+    return st['buf'][i:i + 1]
+
+
+def amax_of(t):
+    return getattr(t, 'y4_amax', None) if t is not None else None
+
+
+def tag_amax(t, cell):
+    if cell is not None and t is not None:
+        t.y4_amax = cell
+    return t
+
+
+def amax_raw(t, valid_channels=None):
+    """max|finite element| of an NHWC activation (one read pass) into a fresh cell."""
+    B, C, H, W = t.shape
+    t, ld = as_nhwc(t, need_vec4=False)
+    cell = torch.empty(1, dtype=torch.int32, device=t.device)
+    check(lib().y4_amax_f32(_ptr(t), ld, B * H * W, int(valid_channels or C), _ptr(cell), _stream()), 'amax')
+    return cell
+
+
+def amax_merge(dst, src):
+    check(lib().y4_amax_merge_u32(_ptr(dst), _ptr(src), _stream()), 'amax_merge')
+
+
 def conv_out_hw(H, W, k, s):
     p = (k - 1) // 2
     return (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
 
 
 # ------------------------------------------------------------------ raw op wrappers (no autograd)
-def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None):
+def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
+                 out_amax=None):
     L = lib()
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -143,7 +195,8 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
     check(L.y4_conv2d_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, B, H, W, Cin, Cout, k, s,
-                              _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _ptr(x_amax), _stream()), 'conv2d_fwd')
+                              _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _ptr(x_amax), _ptr(out_amax),
+                              _stream()), 'conv2d_fwd')
     return out
 
 
@@ -265,7 +318,7 @@ def _slot_ok(out, shape):
             and out.data_ptr() % 16 == 0)
 
 
-def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None):
+def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None):
     L = lib()
     B, C, H, W = y.shape
     y, ldy = as_nhwc(y)
@@ -274,11 +327,11 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None):
     if residual is not None:
         residual, ldr = as_nhwc(residual)
     check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act],
-                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _stream()), 'bn_act_fwd')
+                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), _stream()), 'bn_act_fwd')
     return z
 
 
-def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None):
+def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None):
     """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
     L = lib()
     B, C, H, W = y.shape
@@ -294,7 +347,7 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
-                              _ptr(ws), nbytes, _stream()), 'bn_act_bwd')
+                              _ptr(ws), nbytes, _ptr(out_amax), _stream()), 'bn_act_bwd')
     return dy, dgamma, dbeta
 
 
@@ -370,14 +423,14 @@ def join_side_stream(device=None):
     _ASYNC['join_queued'] = False
 
 
-def _wgrad_to_param(x, dy, param, k, s):
+def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None):
     """wgrad on the side stream, accumulated straight into param.grad (autograd gets None for this input)."""
     main = torch.cuda.current_stream(x.device)
     side = side_stream(x.device)
     ev = main.record_event()
     with torch.cuda.stream(side):
         side.wait_event(ev)
-        dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s)
+        dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s, x_amax=x_amax, dy_amax=dy_amax)
         if param.grad is None:
             dw.record_stream(main)          # allocated in the side stream's pool, consumed (and freed) on the main one
             param.grad = dw
@@ -408,45 +461,65 @@ class ConvBNActFn(torch.autograd.Function):
         # full gc.collect() breaks (round 1: +4.96 GiB of concat buffers per training step).  ctx keeps the
         # scalars and parameter handles backward needs, nothing else.
         dest = cfg.pop('out', None)
-        ctx.cfg = {key: cfg.get(key) for key in ('k', 's', 'act', 'gamma_param', 'beta_param', 'weight_param')}
+        ctx.cfg = {key: cfg.get(key) for key in ('k', 's', 'act', 'gamma_param', 'beta_param', 'weight_param',
+                                                 'dres_put', 'dres_take')}
         ctx.x_shape = tuple(x.shape)
         ctx.has_res = residual is not None
+        # conv mode 3: operand maxima travel with the tensors (see "operand maxima" above)
+        f16 = f16x2_mode() and x.shape[1] != 3
+        x_amax = cfg.get('x_amax') if f16 else None
+        z_amax = None
+        io = cfg.get('io')
+        if f16 and x_amax is None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            x_amax = amax_raw(x)                     # needed twice (forward, wgrad): one pass here instead of two inside
+        ctx.x_amax = x_amax
         if bn and training:
             if x.shape[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[1] <= 1:
                 raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
             y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
-                                                   cfg['nbt'], cfg['momentum'], cfg['eps'])
-            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest)
+                                                   cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax)
+            if f16x2_mode():
+                z_amax = cfg.get('out_amax') if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
+                if z_amax is None:
+                    z_amax = new_amax(x.device)
+            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
         elif bn:
             scale, shift = bn_fold_raw(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
             o = dest
             Ho, Wo = conv_out_hw(x.shape[2], x.shape[3], k, s)
-            z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual,
-                             out=o if _slot_ok(o, (x.shape[0], weight.shape[0], Ho, Wo)) else None)
+            o = o if _slot_ok(o, (x.shape[0], weight.shape[0], Ho, Wo)) else None
+            if f16:
+                z_amax = (cfg.get('out_amax') if o is not None else None) or new_amax(x.device)
+            z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual, out=o, x_amax=x_amax, out_amax=z_amax)
             ctx.mode = 'bn_eval'
         else:
-            z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32)
+            z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32, x_amax=x_amax)
             if act != 'linear':
                 ctx.mode = 'nobn_act'
             else:
                 ctx.save_for_backward(x, weight)
                 ctx.mode = 'nobn_linear'
+        if io is not None:
+            io['z_amax'] = z_amax
         return z
 
     @staticmethod
     def backward(ctx, dz):
         cfg = ctx.cfg
         k, s, act = cfg['k'], cfg['s'], cfg['act']
+        f16 = f16x2_mode() and ctx.x_shape[1] != 3
+        dy_amax = None
         if ctx.mode == 'bn_train':
             x, weight, y, mean, invstd, gamma, beta = ctx.saved_tensors
             gp, bp = cfg.get('gamma_param'), cfg.get('beta_param')
             sink = (gp is not None and bp is not None and getattr(gp, '_y4_grad_fresh', False)
                     and getattr(bp, '_y4_grad_fresh', False) and gp.grad is not None and bp.grad is not None
                     and ctx.needs_input_grad[3] and ctx.needs_input_grad[4])
+            dy_amax = new_amax(dz.device) if f16 else None
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
-                                               gp.grad if sink else None, bp.grad if sink else None)
+                                               gp.grad if sink else None, bp.grad if sink else None, out_amax=dy_amax)
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
                 gp._y4_grad_fresh = bp._y4_grad_fresh = False
@@ -459,30 +532,42 @@ class ConvBNActFn(torch.autograd.Function):
             dy = dz
             dgamma = dbeta = None
             dbias = bias_grad_raw(dz) if ctx.needs_input_grad[2] else None
+            if f16:
+                dy_amax = amax_raw(dy)               # used by dgrad and wgrad: one pass instead of two
         else:
             raise Y4Error(f'backward through ConvBNAct in mode {ctx.mode} is not implemented '
                           '(the reference trains in train mode only, yolo/engine/build.py:45)')
         dx = None
+        take = cfg.get('dres_take')
+        skip_grad = take.pop('dres', None) if take is not None else None
         if ctx.needs_input_grad[0]:
             if ctx.x_shape[1] == 3:
                 raise Y4Error('gradient wrt the network input (stem, Cin=3) is not implemented')
-            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s)
+            # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
+            # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
+            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad)
+        elif skip_grad is not None:
+            raise Y4Error('a parked skip gradient has no consumer (input of the 1x1 conv does not require grad)')
         dw = None
         if ctx.needs_input_grad[1]:
             param = cfg.get('weight_param')
             if _ASYNC['on'] and param is not None and param.requires_grad:
-                _wgrad_to_param(x, dy, param, k, s)          # lands in param.grad on the side stream
+                _wgrad_to_param(x, dy, param, k, s, ctx.x_amax, dy_amax)          # lands in param.grad on the side stream
             elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
                 # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place
                 # (no temporary, no accumulate pass); the bucket is told directly, autograd gets None
                 param._y4_grad_fresh = False
-                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad)
+                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad, x_amax=ctx.x_amax, dy_amax=dy_amax)
                 if got is not param.grad:
                     param.grad.add_(got)
                 param._y4_grad_ready()
             else:
-                dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s)
+                dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, x_amax=ctx.x_amax, dy_amax=dy_amax)
         dres = dz if ctx.has_res else None
+        put = cfg.get('dres_put')
+        if dres is not None and put is not None:
+            put['dres'] = dres                      # consumed by the unit's 1x1 conv (dres_take); autograd sees no gradient
+            dres = None
         return dx, dw, dbias, dgamma, dbeta, dres, None
 
 
@@ -506,7 +591,9 @@ class Fork2Fn(torch.autograd.Function):
 def fork(x):
     if not (torch.is_grad_enabled() and x.requires_grad):
         return x, x
-    return Fork2Fn.apply(x)
+    a, b = Fork2Fn.apply(x)
+    cell = amax_of(x)
+    return tag_amax(a, cell), tag_amax(b, cell)
 
 
 class CatBuffer:
@@ -518,9 +605,11 @@ class CatBuffer:
         self.sizes = list(sizes)
         self.buf = empty_nhwc(B, sum(self.sizes), H, W, device)
         self.offsets = [sum(self.sizes[:i]) for i in range(len(self.sizes))]
+        # conv mode 3: ONE operand-maximum cell for the whole buffer, every producer folds into it
+        self.amax = new_amax(device) if (device.type == 'cuda' and f16x2_mode()) else None
 
     def slot(self, i):
-        return self.buf[:, self.offsets[i]:self.offsets[i] + self.sizes[i]]
+        return tag_amax(self.buf[:, self.offsets[i]:self.offsets[i] + self.sizes[i]], self.amax)
 
 
 class CatFn(torch.autograd.Function):
@@ -553,7 +642,16 @@ class CatFn(torch.autograd.Function):
 
 
 def cat(xs, into=None):
-    return CatFn.apply(into, *xs)
+    out = CatFn.apply(into, *xs)
+    if into is not None and into.amax is not None and out.data_ptr() == into.buf.data_ptr():
+        for t in xs:                                 # inputs that were copied in bring their own maximum
+            cell = amax_of(t)
+            if cell is None:
+                cell = amax_raw(t)
+            if cell.data_ptr() != into.amax.data_ptr():
+                amax_merge(into.amax, cell)
+        tag_amax(out, into.amax)
+    return out
 
 
 def cat_buffer(like, sizes, hw=None):
@@ -599,6 +697,11 @@ class SppPoolCatFn(torch.autograd.Function):
         for sl, idx, ks in ((g[:, 0:C], idx5, 5), (g[:, C:2 * C], idx9, 9), (g[:, 2 * C:3 * C], idx5, 5)):
             check(L.y4_maxpool_s1_bwd_f32(_ptr(sl), ldg, _ptr(idx), _ptr(dx), ldx, 1, B, H, W, C, ks, st), 'maxpool_bwd')
         return dx
+
+
+def spp_pool_cat(x):
+    """cat([pool5(x), pool9(x), pool5(x), x]); max|out| = max|x| (pooling selects elements)."""
+    return tag_amax(SppPoolCatFn.apply(x), amax_of(x))
 
 
 class MaxPoolS1Fn(torch.autograd.Function):

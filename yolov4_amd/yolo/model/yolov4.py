@@ -57,7 +57,7 @@ class SPPBlock(nn.Module):
         self.conv2 = ConvBNAct(2048, 512, 1, 1, act=L)
 
     def forward(self, x):
-        return self.conv2(ops.SppPoolCatFn.apply(self.conv1(x)))
+        return self.conv2(ops.spp_pool_cat(self.conv1(x)))
 
 
 class Upsample(nn.Module):
@@ -68,13 +68,24 @@ class Upsample(nn.Module):
         slot = ops.Slot(out) if out is not None else None
         Ht, Wt = int(target_size[2]), int(target_size[3])
         if Ht == 2 * x.shape[2] and Wt == 2 * x.shape[3]:
-            return ops.Upsample2xFn.apply(x, slot)                 # the YOLOv4 neck at S % 32 == 0
+            return self._tag(ops.Upsample2xFn.apply(x, slot), x, out)      # the YOLOv4 neck at S % 32 == 0
         # any other target (e.g. S = 600: 19 -> 38 -> 75): train = F.interpolate(size=target, nearest) (yolov4.py:85);
         # eval = integer-factor expand whose final view() needs target % input == 0 (yolov4.py:87-90)
         if not self.training and (Ht % x.shape[2] or Wt % x.shape[3]):
             raise RuntimeError(f"shape '[{x.shape[0]}, {x.shape[1]}, {Ht}, {Wt}]' is invalid for input of size "
                                f"{x.shape[0] * x.shape[1] * (Ht // x.shape[2]) * x.shape[2] * (Wt // x.shape[3]) * x.shape[3]}")
-        return ops.UpsampleNearestFn.apply(x, Ht, Wt, not self.training, slot)
+        return self._tag(ops.UpsampleNearestFn.apply(x, Ht, Wt, not self.training, slot), x, out)
+
+    @staticmethod
+    def _tag(y, x, out):
+        """conv mode 3: max|upsampled| = max|x|; written into a concat slot it folds into that buffer's shared cell"""
+        cell, shared = ops.amax_of(x), ops.amax_of(out)
+        if shared is not None and y.data_ptr() == out.data_ptr():
+            if cell is None:
+                cell = ops.amax_raw(x)
+            ops.amax_merge(shared, cell)
+            return ops.tag_amax(y, shared)
+        return ops.tag_amax(y, cell)
 
 
 class FPNBlock(nn.Module):
