@@ -99,7 +99,7 @@ class ConvTimer:
             mode = args_conv_mode()
             kern = {'f32': 'conv_wgrad_mfma_f32', 'f16x2': 'conv_wgrad_f16x2'}.get(mode, 'conv_wgrad_bf16x3')
             tn, tj = (64 if Cout <= 64 else 128), (64 if k * k * x.shape[1] <= 64 else 128)
-            tail = {'f32': '>', 'bf16': ', 1>', 'bf16x3': ', 3>', 'f16x2': f", {os.environ.get('Y4_F16X2_SHAPE', '32')}>"}[mode]
+            tail = {'f32': '>', 'bf16': ', 1>', 'bf16x3': ', 3>', 'f16x2': f", {os.environ.get('Y4_F16X2_SHAPE', '16')}>"}[mode]
             timer.sym = 'conv_stem_wgrad_kernel' if x.shape[1] == 3 else f'{kern}<{tn}, {tj}' + tail
             return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k, (x.shape[1], Cout, k, s, x.shape[2])
 
@@ -150,7 +150,7 @@ def gather_symbol(transposed, M, N, Cs, Cs_valid, k, stride, ld):
         return 'conv_stem_fwd_bf16x3_kernel' if mode in ('bf16x3', 'f16x2') else 'conv_stem_fwd_kernel'
     tr = 'true' if transposed else 'false'
     if mode == 'f16x2':
-        ms = int(os.environ.get('Y4_F16X2_SHAPE', '32'))
+        ms = int(os.environ.get('Y4_F16X2_SHAPE', '16'))
         if (k == 1 and stride == 1 and Cs in (32, 64, 128) and Cs_valid == Cs and N <= 128 and M * ld * 4 < 0xfffffff0
                 and M >= 128 * 1024):
             nt = (N + 31) // 32

@@ -325,16 +325,25 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // the skip / fan-in operand of this tile column is fetched as one batch BEFORE the stores (the compiler may
+            // not move a load across a store that might alias it: one exposed round trip per element otherwise)
+            int mm[ACCN];
+            float rr[ACCN];
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
                 const int rl = MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e;
+                mm[e] = row_m[wm * WTM + i * MS + rl];
+                rr[e] = (g.res && nok && mm[e] >= 0) ? g.res[(long long)mm[e] * g.ldr + n] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) {
                 const float raw = acc0[i][j][e] * un + acc1[i][j][e] * un1;
                 acc0[i][j][e] = raw;                       // kept for the BN statistics below
-                const int m = row_m[wm * WTM + i * MS + rl];
+                const int m = mm[e];
                 if (nok && m >= 0) {
                     float v = raw * sc + sh;
                     v = y4_act(v, g.act);
-                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    v += rr[e];
                     g.dst[(long long)m * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
             const unsigned o = (unsigned)__shfl_xor((int)out_max, off, 64);
             out_max = o > out_max ? o : out_max;
         }
-        if (lane == 0 && out_max) atomicMax(g.dst_amax, out_max);
+        if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
     }
     if (!TRANSPOSED && g.stats) {
         float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the K loop ended with a barrier
@@ -672,6 +681,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + fr;
             const bool nok = n < g.N;
+            // skip / fan-in operand: one batch of 16 loads ahead of the stores, except at NT = 4 where the two accumulator
+            // sets leave no registers for it (the batch would spill)
+            constexpr bool BATCH = NT < 4;
+            float rr[BATCH ? 16 : 1];
+            if constexpr (BATCH) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    rr[e] = (g.res && nok && m < g.M) ? g.res[(long long)m * g.ldr + n] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float raw = acc0[j][e] * un + acc1[j][e] * un1;
@@ -680,7 +700,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
                 if (nok && m < g.M) {
                     float v = raw * sc[j] + sh[j];
                     v = y4_act(v, g.act);
-                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    if constexpr (BATCH) v += rr[e];
+                    else if (g.res) v += g.res[(long long)m * g.ldr + n];
                     g.dst[(long long)m * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
@@ -719,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
             const unsigned o = (unsigned)__shfl_xor((int)out_max, off, 64);
             out_max = o > out_max ? o : out_max;
         }
-        if (lane == 0 && out_max) atomicMax(g.dst_amax, out_max);
+        if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
     }
     if (g.stats) {                                        // one partial row per block: [gridDim][2][N]
         __syncthreads();                                  // every wave is done with the filter planes
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
         const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 __global__ __launch_bounds__(256) void amax_strided_kernel(const float* __restrict__ x, long long ld, long long M, int C,
                                                            unsigned* __restrict__ out) {
@@ -864,13 +885,13 @@ __global__ __launch_bounds__(256) void amax_strided_kernel(const float* __restri
         const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
         m = o > m ? o : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 __global__ void amax_merge_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned v = *src; if (v) atomicMax(dst, v); }
 }
 
-int g_f16x2_shape = 32;          // MFMA shape of the f16x2 kernels: 32 (32x32x16) or 16 (16x16x32); Y4_F16X2_SHAPE overrides
+int g_f16x2_shape = 16;          // MFMA shape of the f16x2 kernels: 32 (32x32x16) or 16 (16x16x32); Y4_F16X2_SHAPE overrides
 
 template <int BM, int BN, int WM, int WN, bool TR, int MS>
 int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {

@@ -707,9 +707,9 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
     return Y4_OK;
 }
 
-int g_conv_mode = 1;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs; default),
+int g_conv_mode = 3;          // 0: fp32 MFMA (exact fma chain), 1: split-bf16 x3 (fp32-grade, 6 bf16 MFMAs),
                               // 2: plain bf16 operands (RN), fp32 accumulate -- mixed precision, BASELINE config 5
-                              // 3: split-fp16 x2 (fp32-grade, 3 fp16 MFMAs, per-tensor power-of-two scale; conv_f16x2.hip)
+                              // 3: split-fp16 x2 (fp32-grade, 3 fp16 MFMAs, per-tensor power-of-two scale; conv_f16x2.hip) -- default
 
 // ---------------------------------------------------------------- streaming 1x1 kernel (small K, small N)
 // The 1x1 layers on the 304^2 / 152^2 maps are HBM-bound (K, N <= 128: < 64 flop per byte); the tile machinery
