@@ -745,5 +745,10 @@ def test_eval_batch_independence_at_config2_size(dev, golden, hip_model):
                 assert (da is None) == (db is None)
                 if da is not None:
                     assert da.shape == db.shape
-                    assert torch.equal(da[:, 6], db[:, 6])
-                    close(da[:, :6], db[:, :6], 2e-5, 1e-4)
+                    assert torch.equal(da[:, 6], db[:, 6])                   # same classes, same count per class
+                    # scores agree to rounding only, so two near-tied boxes of one class may swap places in the
+                    # score-ordered output: compare each class as a set (rows sorted by x1)
+                    a, r = da.cpu().numpy(), db.cpu().numpy()
+                    for c in np.unique(r[:, 6]):
+                        aa, rr = a[a[:, 6] == c], r[r[:, 6] == c]
+                        close(aa[np.argsort(aa[:, 0])][:, :6], rr[np.argsort(rr[:, 0])][:, :6], 2e-5, 1e-4)

@@ -593,6 +593,324 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     }
 }
 
+// ==================================================================================== 3x3 stride-1 "halo" kernel
+// The gather kernel fetches and splits every input pixel once per filter tap (9x) and per N-tile.  For 3x3 / stride 1 /
+// pad 1 layers on maps up to 76 px wide this kernel stages, per 32-channel chunk, the PATCH of input pixels that the 128
+// output pixels of its M-tile touch -- once -- and runs the nine taps out of it:
+//   * M-tiles never cross an image: 128 consecutive output pixels (h, w) of one image (the last tile of an image is
+//     partial).  In the zero-padded image (H+2) x (W+2), output pixel (h, w) and tap (r, q) read padded position
+//     (h + r, w + q) [dgrad: (h + 2 - r, w + 2 - q)], i.e. flat padded index base(h, w) + r Wp + q: the tap offset is
+//     the same for every row of the tile, and the halo zeros are part of the patch (written at staging time by the
+//     buffer loads' out-of-range zero fill) -- no masks in the MFMA loop.
+//   * patch = padded flat positions [base(first pixel), base(last pixel) + 2 Wp + 2]: <= 290 rows of 32 channels for
+//     W <= 76 (2 fp16 planes x 64 B: 37 KB), single stage, restaged every 9 taps; filter tiles double buffered per
+//     tap with register prefetch as in the gather kernel.  71 KB of LDS: two blocks per CU.
+//   * per 9 taps a thread issues <= 10 activation loads and splits <= 40 values instead of 36 loads / 144 values.
+constexpr int HALO_ROWS = 304;                             // patch capacity (rows of 32 channels)
+
+template <int BN, bool TRANSPOSED, int MS>
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, const int tiles_per_img) {
+    constexpr int BM = 128, WM = 2, WN = 2;
+    constexpr int NB = (BN * 4 + 255) / 256;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int TM = WTM / MS, TN = WTN / MS;
+    constexpr int ACCN = MS == 32 ? 16 : 4;
+    constexpr int PP = (HALO_ROWS + 31) / 32;              // patch rows per thread (32 rows x 8 chunks per pass)
+    constexpr int PATCH = 2 * HALO_ROWS * ROWB;            // bytes: 2 planes
+    constexpr int BSTAGE = 2 * BN * ROWB;                  // bytes per filter stage: 2 planes
+    typedef float accv __attribute__((ext_vector_type(ACCN)));
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* const bsm = smem_b + PATCH;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lt = y4_xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    const int mt = lt / g.ntiles, nt = lt - mt * g.ntiles;
+    const int b = mt / tiles_per_img, t = mt - b * tiles_per_img;
+    const int n0 = nt * BN;
+    const int H = g.Hs, W = g.Ws, Wp = W + 2, HW = H * W;
+    const int i0 = t * BM;                                 // first output pixel of the tile inside image b
+    const int cnt = (HW - i0) < BM ? (HW - i0) : BM;       // valid rows of this tile
+    const int h0 = i0 / W, w0 = i0 - h0 * W;
+    const int p_lo = h0 * Wp + w0;                         // padded flat position of (first pixel, tap (0, 0))
+    const int il_last = i0 + cnt - 1;
+    const int h1 = il_last / W, w1 = il_last - h1 * W;
+    const int prow_n = (h1 + 2) * Wp + (w1 + 2) - p_lo + 1;   // patch rows in use (<= HALO_ROWS, checked on the host)
+
+    const unsigned long long img_bytes = (unsigned long long)HW * (unsigned long long)g.lds_ * 4ull;
+    const __amdgpu_buffer_rsrc_t src_rsrc =
+        y4_make_rsrc(reinterpret_cast<const char*>(g.src) + (unsigned long long)b * img_bytes, (unsigned)img_bytes);
+    const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt_planes, g.wt_bytes);
+    const unsigned OOB = 0xffffffffu;
+    const float sa = f16x2_scale(g.src_amax);
+    const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
+    const int lrow = tid >> 3, kc = tid & 7;
+
+    // ---- patch rows of this thread: source offset (or OOB for halo / unused rows) and LDS position, fixed for the kernel
+    unsigned a_off[PP];
+    int a_lds[PP];
+#pragma unroll
+    for (int p = 0; p < PP; ++p) {
+        const int j = p * 32 + lrow;
+        const int pf = p_lo + j;
+        const int hp = pf / Wp, wp = pf - hp * Wp;
+        const bool ok = j < prow_n && hp >= 1 && hp <= H && wp >= 1 && wp <= W;
+        a_off[p] = ok ? (unsigned)((hp - 1) * W + (wp - 1)) * pix_bytes + kc * 16u : OOB;
+        a_lds[p] = j < HALO_ROWS ? j * ROWB + (((kc >> 1) ^ lds_swz<MS>(j)) << 4) + ((kc & 1) << 3) : -1;
+    }
+    // ---- filter chunks of this thread
+    unsigned b_off[NB];
+    int b_lds[NB];
+    const unsigned plane_bytes = (unsigned)g.N * (unsigned)g.K * 2u;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int slot = tid + 256 * i;
+        const int row = slot >> 2, ch = slot & 3;
+        const bool ok = row < BN && (n0 + row) < g.N;
+        b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 2u + ch * 16u : OOB;
+        b_lds[i] = row < BN ? row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
+    }
+    const int CC = g.Cs / 32;
+    const int S = 9 * CC;                                  // steps: s = cc * 9 + tap
+    u32x4 rb[NB][2];
+    int ld_s = 0;
+    auto load_b = [&]() {
+        const int cc = ld_s / 9, tap = ld_s - cc * 9;
+        const unsigned koff = (unsigned)(tap * CC + cc) * 64u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+                rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)(koff + pl * plane_bytes), 0);
+        ++ld_s;
+    };
+    auto store_b = [&](int buf) {
+        unsigned char* bs = bsm + buf * BSTAGE;
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (b_lds[i] >= 0) {
+                *reinterpret_cast<u32x4*>(bs + b_lds[i]) = rb[i][0];
+                *reinterpret_cast<u32x4*>(bs + BN * ROWB + b_lds[i]) = rb[i][1];
+            }
+    };
+    auto stage_patch = [&](int cc) {
+        f32x4 ra[PP];
+#pragma unroll
+        for (int p = 0; p < PP; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)cc * 128u);
+#pragma unroll
+        for (int p = 0; p < PP; ++p) {
+            if (a_lds[p] < 0) continue;
+            f32x4 v = ra[p];
+            if (TRANSPOSED) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (cc * 32 + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
+            }
+            u32x2 hi, lo;
+            split2x4(v, sa, hi, lo);
+            *reinterpret_cast<u32x2*>(smem_b + a_lds[p]) = hi;
+            *reinterpret_cast<u32x2*>(smem_b + HALO_ROWS * ROWB + a_lds[p]) = lo;
+        }
+    };
+
+    accv acc0[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+
+    const int fr = lane & (MS - 1), fq = lane / MS;
+    const int fswb = lds_swz<MS>(fr);
+    const int b_row = (wn * WTN + fr) * ROWB;
+    // patch row (relative to p_lo) of tap (0, 0) for the output pixel of each of this lane's A fragment rows
+    int a_rel[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int il = wm * WTM + i * MS + fr;
+        if (il >= cnt) il = cnt - 1;                       // rows past the image end: computed, never stored
+        const int pix = i0 + il;
+        const int h = pix / W, w = pix - h * W;
+        a_rel[i] = h * Wp + w - p_lo;
+    }
+
+    auto compute = [&](int buf, int tap) {
+        const unsigned char* bs = bsm + buf * BSTAGE;
+        const int r = tap / 3, q = tap - r * 3;
+        const int toff = TRANSPOSED ? (2 - r) * Wp + (2 - q) : r * Wp + q;
+        constexpr int KSN = MS == 32 ? 2 : 1;
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+            const int cb = MS == 32 ? 2 * ks + fq : fq;    // logical 16-B chunk of the 32-deep K-tile
+            const int cob = (cb ^ fswb) << 4;
+            f16x8 fb[TN][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    fb[j][pl] = *reinterpret_cast<const f16x8*>(bs + pl * BN * ROWB + b_row + j * MS * ROWB + cob);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = a_rel[i] + toff;
+                const int ao = row * ROWB + ((cb ^ lds_swz<MS>(row)) << 4);
+                const f16x8 fa0 = *reinterpret_cast<const f16x8*>(smem_b + ao);
+                const f16x8 fa1 = *reinterpret_cast<const f16x8*>(smem_b + HALO_ROWS * ROWB + ao);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (MS == 32) {
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa1, fb[j][0], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
+                        acc0[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
+                    } else {
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[j][0], acc1[i][j], 0, 0, 0);
+                        acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
+                        acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    load_b();
+    store_b(0);
+    if (S > 1) load_b();
+    for (int s = 0; s < S; ++s) {
+        const int cc = s / 9, tap = s - cc * 9;
+        if (tap == 0) {
+            stage_patch(cc);                               // every wave left the previous patch at the last barrier
+            __syncthreads();
+        }
+        if (s + 1 < S) store_b((s + 1) & 1);
+        if (s + 2 < S) load_b();
+        compute(s & 1, tap);
+        __syncthreads();
+    }
+
+    // ---- epilogue (as the gather kernel; output pixel m = b HW + i0 + row, rows >= cnt are not part of the image)
+    const float un = f16x2_unscale(g.src_amax) * f16x2_unscale(g.wt_amax);
+    const float un1 = un * (1.0f / 2048.0f);
+    const long long mbase = (long long)b * HW + i0;
+    unsigned out_max = 0u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * MS + fr;
+        const bool nok = n < g.N;
+        const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
+        const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float rr[ACCN];
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) {
+                const int rl = wm * WTM + i * MS + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
+                rr[e] = (g.res && nok && rl < cnt) ? g.res[(mbase + rl) * g.ldr + n] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) {
+                const int rl = wm * WTM + i * MS + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
+                const bool rok = rl < cnt;
+                const float raw = rok ? acc0[i][j][e] * un + acc1[i][j][e] * un1 : 0.f;
+                acc0[i][j][e] = raw;                       // kept for the BN statistics below (0 for rows past the image)
+                if (nok && rok) {
+                    float v = raw * sc + sh;
+                    v = y4_act(v, g.act);
+                    v += rr[e];
+                    g.dst[(mbase + rl) * g.ldd + n] = v;
+                    const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
+                    if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                }
+            }
+        }
+    }
+    if (!TRANSPOSED && g.dst_amax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)out_max, off, 64);
+            out_max = o > out_max ? o : out_max;
+        }
+        if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
+    }
+    if (!TRANSPOSED && g.stats) {
+        float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the step loop ended with a barrier
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < ACCN; ++e) { const float v = acc0[i][j][e]; cs += v; css += v * v; }
+            if constexpr (MS == 16) {
+                cs += __shfl_xor(cs, 16, 64);
+                css += __shfl_xor(css, 16, 64);
+            }
+            cs += __shfl_xor(cs, 32, 64);
+            css += __shfl_xor(css, 32, 64);
+            if (fq == 0) {
+                const int c = wn * WTN + j * MS + fr;
+                red[(wm * BN + c) * 2 + 0] = cs;
+                red[(wm * BN + c) * 2 + 1] = css;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 256) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
+            const int n = n0 + c;
+            if (n < g.N) {
+                g.stats[((long long)mt * 2 + 0) * g.N + n] = cs;
+                g.stats[((long long)mt * 2 + 1) * g.N + n] = css;
+            }
+        }
+    }
+}
+
+// rows of the patch of the worst tile of an H x W image (tiles start at multiples of 128 pixels)
+int halo_patch_rows(int H, int W) {
+    const int HW = H * W, Wp = W + 2;
+    int worst = 0;
+    for (int i0 = 0; i0 < HW; i0 += 128) {
+        const int i1 = (i0 + 127 < HW ? i0 + 127 : HW - 1);
+        const int h0 = i0 / W, w0 = i0 % W, h1 = i1 / W, w1 = i1 % W;
+        const int n = (h1 + 2) * Wp + (w1 + 2) - (h0 * Wp + w0) + 1;
+        if (n > worst) worst = n;
+    }
+    return worst;
+}
+
+bool halo_ok(const ConvGeom& g) {
+    static const bool off = getenv("Y4_NO_HALO") != nullptr;
+    if (off || g.k != 3 || g.stride != 1 || g.pad != 1 || !g.wt_planes) return false;
+    if (g.N <= 64 || g.Cs % 32 != 0 || g.Hd != g.Hs || g.Wd != g.Ws) return false;
+    if ((unsigned long long)g.Hs * g.Ws * (unsigned long long)g.lds_ * 4ull >= 0xfffffff0ull) return false;
+    return halo_patch_rows(g.Hs, g.Ws) <= HALO_ROWS;
+}
+
+template <bool TR, int MS>
+int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
+    constexpr int BN = 128;
+    ConvGeom g = g0;
+    const int tiles_per_img = (g.Hs * g.Ws + 127) / 128;
+    g.mtiles = g.B * tiles_per_img;
+    g.ntiles = (g.N + BN - 1) / BN;
+    if ((unsigned long long)g.N * g.K * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+    g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
+    if (nparts) *nparts = g.mtiles;
+    const size_t smem = 2ull * HALO_ROWS * ROWB + 2ull * 2 * BN * ROWB;
+    auto kern = conv3x3_halo_f16x2<BN, TR, MS>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(256), smem, st, g, tiles_per_img);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
 // ==================================================================================== streaming 1x1 (small K, small N)
 // The 1x1 layers on the 304^2 / 152^2 / 76^2 maps with K, N <= 128 are HBM-bound; the whole filter (2 fp16 planes)
 // stays in LDS for the life of a persistent block and every wave streams its own 32 pixel rows from global memory
@@ -681,17 +999,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + fr;
             const bool nok = n < g.N;
-            // skip / fan-in operand: one batch of 16 loads ahead of the stores, except at NT = 4 where the two accumulator
-            // sets leave no registers for it (the batch would spill)
-            constexpr bool BATCH = NT < 4;
-            float rr[BATCH ? 16 : 1];
-            if constexpr (BATCH) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mbase + (e & 3) + 8 * (e >> 2);
-                    rr[e] = (g.res && nok && m < g.M) ? g.res[(long long)m * g.ldr + n] : 0.f;
-                }
-            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float raw = acc0[j][e] * un + acc1[j][e] * un1;
@@ -700,8 +1007,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
                 if (nok && m < g.M) {
                     float v = raw * sc[j] + sh[j];
                     v = y4_act(v, g.act);
-                    if constexpr (BATCH) v += rr[e];
-                    else if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    if (g.res) v += g.res[(long long)m * g.ldr + n];
                     g.dst[(long long)m * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
@@ -849,6 +1155,22 @@ __global__ __launch_bounds__(256) void f16x2_transpose_split_filter_kernel(const
 
 // max |finite element| over the first C channels of an NHWC tensor with pitch: bit pattern, folded with atomicMax
 // (order independent -> deterministic) into a word the caller has zeroed (or that already holds a lower bound)
+// one atomic per BLOCK (waves folded through LDS), and only when it would raise the word
+__device__ __forceinline__ void amax_block_commit(unsigned m, unsigned* out) {
+    __shared__ unsigned wmax[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        const unsigned v = a > b ? a : b;
+        if (v > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, v);
+    }
+}
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, long long ld, long long M, int C,
                                                    unsigned* __restrict__ out) {
     unsigned m = 0u;
@@ -864,12 +1186,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
             if (c + e < C && b < 0x7f800000u && b > m) m = b;
         }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
-        m = o > m ? o : m;
-    }
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+    amax_block_commit(m, out);
 }
 __global__ __launch_bounds__(256) void amax_strided_kernel(const float* __restrict__ x, long long ld, long long M, int C,
                                                            unsigned* __restrict__ out) {
@@ -880,12 +1197,7 @@ __global__ __launch_bounds__(256) void amax_strided_kernel(const float* __restri
         const unsigned b = __float_as_uint(x[row * ld + (i - row * C)]) & 0x7fffffffu;
         if (b < 0x7f800000u && b > m) m = b;
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
-        m = o > m ? o : m;
-    }
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+    amax_block_commit(m, out);
 }
 __global__ void amax_merge_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned v = *src; if (v) atomicMax(dst, v); }
@@ -994,6 +1306,10 @@ namespace y4 {
 
 int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts) {
     if (stream1x1_f16x2_ok(g)) return dispatch_stream1x1_f16x2(g, st, nparts);
+    if (halo_ok(g)) {
+        if (f16x2_shape() == 16) return transposed ? launch_halo_f16x2<true, 16>(g, st, nparts) : launch_halo_f16x2<false, 16>(g, st, nparts);
+        return transposed ? launch_halo_f16x2<true, 32>(g, st, nparts) : launch_halo_f16x2<false, 32>(g, st, nparts);
+    }
     if (f16x2_shape() == 16)
         return transposed ? dispatch_gather_f16x2<true, 16>(g, st, nparts) : dispatch_gather_f16x2<false, 16>(g, st, nparts);
     return transposed ? dispatch_gather_f16x2<true, 32>(g, st, nparts) : dispatch_gather_f16x2<false, 32>(g, st, nparts);
@@ -1035,11 +1351,11 @@ int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax
     // 16-B loads when every row starts on a 16-B boundary and a row's last vector stays inside its pitch
     if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ((C + 3) & ~3) <= ld) {
         const long long total = M * ((C + 3) / 4);
-        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        const int blocks = (int)((total + 1023) / 1024 > 1024 ? 1024 : (total + 1023) / 1024);
         hipLaunchKernelGGL(amax_kernel, dim3(blocks), dim3(256), 0, st, x, ld, M, C, amax_bits);
     } else {
         const long long total = M * C;
-        const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+        const int blocks = (int)((total + 1023) / 1024 > 1024 ? 1024 : (total + 1023) / 1024);
         hipLaunchKernelGGL(amax_strided_kernel, dim3(blocks), dim3(256), 0, st, x, ld, M, C, amax_bits);
     }
     Y4_CHECK_LAUNCH();

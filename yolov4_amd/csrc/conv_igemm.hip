@@ -1810,7 +1810,9 @@ size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2)) return 0;
     const int pad = (k - 1) / 2;
     const long long M = (long long)B * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-    const long long rows = Cin == 3 ? (M + 255) / 256 : (M + 63) / 64;      // smallest M-tile of any variant
+    long long rows = Cin == 3 ? (M + 255) / 256 : (M + 63) / 64;            // smallest M-tile of any variant
+    const long long per_img = (long long)B * ((M / B + 127) / 128);         // the 3x3 halo kernel tiles image by image
+    if (per_img > rows) rows = per_img;
     return (size_t)rows * 2 * Cout * sizeof(float);
 }
 

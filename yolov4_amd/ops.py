@@ -577,6 +577,10 @@ class Fork2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        # a branch without gradient must arrive as None, not as a materialised zero tensor (which would cost a fill,
+        # a layout repack and an add): e.g. the skip branch of a ResBlock unit, whose gradient is folded into the
+        # 1x1 conv's dgrad epilogue (ConvBNActFn dres_put / dres_take)
+        ctx.set_materialize_grads(False)
         return x.view_as(x), x.view_as(x)
 
     @staticmethod
