@@ -53,6 +53,9 @@ def parse():
                     help='conv arithmetic: 2-piece fp16 split (fp32-grade, 3 MFMAs per product, default), exact 3-way bf16 '
                          'split (6 MFMAs), the fp32 MFMA fma chain, or plain bf16 operands (mixed precision)')
     ap.add_argument('--conv-table', default=None, help='write a per-shape conv timing table to this file')
+    ap.add_argument('--infer', action='store_true',
+                    help='BASELINE configs[1] instead of the headline: eval forward + YOLO decode + postprocess/NMS at '
+                         '--size, --batch 32 by default; reports images/sec and achieved GB/s of the decode / NMS kernels')
     return ap.parse_args()
 
 
@@ -266,8 +269,102 @@ def cpu_baseline(size, batch):
                       f'torch threads {threads}, host cpus {os.cpu_count()}'}
 
 
+def infer_main(args):
+    """BASELINE configs[1]: 1xMI355X inference, 608x608 bs=32 (val.py path: eval forward -> postprocess).  One JSON line:
+    images/sec of forward + postprocess, and for the HBM-bound head kernels the achieved GB/s against their algorithmic
+    bytes (decode reads + writes B*N*85*4 B = 15.47 MB/img; the candidate count reads it once more), measured
+    live with HIP events on the launch stream."""
+    import recipe
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd._lib import lib
+    from yolov4_amd.yolo.model.yolov4 import YOLOv4
+    from yolov4_amd.yolo.util import utils as U
+    yolov4_amd.set_conv_mode(args.conv_mode)
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
+    torch.cuda.set_device(dev)
+    B, S = (args.batch if args.batch != 64 else 32), args.size
+    m = YOLOv4(recipe.MODEL_CFG, device=dev)
+    sd = m.state_dict()
+    recipe.fill_state_dict_(sd, 1234)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    recipe.calibrate_bn_(m, recipe.randn((8, 3, S, S), 77).to(dev))      # random weights need statistics at this size
+    m.eval()
+    x = recipe.randn((B, 3, S, S), 78).to(dev)
+    rec = {}
+
+    def bracket(obj, name, key):
+        fn = getattr(obj, name)
+
+        def inner(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **kw)
+            e1.record()
+            rec.setdefault(key, []).append((e0, e1))
+            return out
+        setattr(obj, name, inner)
+
+    bracket(ops, 'yolo_decode_eval', 'decode')
+    L = lib()
+    bracket(L, 'y4_post_count_f32', 'post_count')
+    bracket(L, 'y4_post_nms_f32', 'post_fill_sort_nms')
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            out = m(x)
+        sc = (out[..., 4:5] * out[..., 5:]).flatten()
+        # confidence threshold giving ~500 candidates per image (SURVEY 8d config 2: survivors 1e2..1e3 per image)
+        thr = float(torch.quantile(sc[torch.randint(0, sc.numel(), (1000000,), device=dev)], 1 - 500.0 / (out.shape[1] * 80)))
+        U.postprocess(out.clone(), 80, thr, 0.4)
+        rec.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tf = tp = 0.0
+        for _ in range(args.steps):
+            a = time.perf_counter()
+            out = m(x)
+            torch.cuda.synchronize()
+            b_ = time.perf_counter()
+            det = U.postprocess(out, 80, thr, 0.4)
+            torch.cuda.synchronize()
+            tf += b_ - a
+            tp += time.perf_counter() - b_
+        dt = time.perf_counter() - t0
+    N = out.shape[1]
+    ms = lambda key: sum(e0.elapsed_time(e1) for e0, e1 in rec[key]) / args.steps
+    dec_bytes = 2.0 * B * N * 85 * 4
+    cnt_bytes = 1.0 * B * N * 85 * 4 + B * N * 4 * 4        # reads every score once, rewrites the 4 box columns (xyxy)
+    surv = sum(0 if d is None else len(d) for d in det) / B
+    outj = {'metric': f'images/sec inference @{S}x{S} bs={B} (eval forward + YOLO decode + postprocess / per-class NMS)',
+            'value': B * args.steps / dt, 'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'configs[1]: 1xMI355X inference, {S}x{S} bs={B}, BN folded into the conv epilogues, random '
+                                   f'weights with BatchNorm statistics calibrated at {S}', 'conv_arithmetic': MODES[args.conv_mode]['text'],
+                       'conf_thre': thr, 'nms_thre': 0.4, 'survivors_per_img': surv, 'boxes_per_img': N,
+                       'forward_ms': tf / args.steps * 1e3, 'postprocess_ms': tp / args.steps * 1e3,
+                       'forward_images_per_sec': B * args.steps / tf,
+                       'forward_conv_tflops': B * args.steps / tf * 134.422e9 * (S / 608.0) ** 2 / 1e12},
+            'roofline': {'bound': 'hbm', 'kernel': 'yolo_decode_kernel<true> (3 launches per batch)',
+                         'achieved': dec_bytes / (ms('decode') * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': dec_bytes / (ms('decode') * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                         'algorithmic_bytes_per_batch': dec_bytes, 'ms_per_batch': ms('decode'),
+                         'measured': 'LIVE: HIP events around the three decode launches of every timed batch',
+                         'other_kernels': {
+                             'post_count_kernel (xywh->xyxy + candidate count)': {
+                                 'ms_per_batch': ms('post_count'), 'GB/s': cnt_bytes / (ms('post_count') * 1e-3) / 1e9,
+                                 'algorithmic_bytes_per_batch': cnt_bytes},
+                             'post_fill + segment sort + post_nms (data dependent)': {
+                                 'ms_per_batch': ms('post_fill_sort_nms'), 'candidates_per_img_target': 500,
+                                 'survivors_per_img': surv}}}}
+    print(json.dumps(outj))
+
+
 def main():
     args = parse()
+    if args.infer:
+        return infer_main(args)
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))

@@ -398,8 +398,16 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
 // D[n][j] = sum_p dy[p][n] * xg[p][j]; both operands transposed into LDS as [n or j][32 pixels] rows while being
 // split: each thread owns one 4-pixel x 4-channel block of each operand per 32-pixel chunk (4 coalesced 16-B loads,
 // a 4x4 register transpose folded into the fp16 packing, 8 ds_write_b64).
+//
+// Ping-pong: ONE 8-wave block per CU.  Waves 0-3 ("group 0") and waves 4-7 ("group 1") -- wave w and w + 4 share a
+// SIMD -- both own the WHOLE output tile and take alternate 32-pixel chunks; while one group runs the 48 MFMAs of
+// its chunk out of its LDS stage, the other splits and writes its next chunk into the other stage and issues the
+// global loads of the one after (two phases of flight time).  One barrier per phase.  Two independent 4-wave blocks
+// per CU ran in lockstep instead (matrix phases coincided, then both staged: PMC MFMA-busy 0.31); here the matrix
+// pipe of every SIMD always has a wave feeding it while its partner does the VALU / LDS-write work.  The two partial
+// tiles are added through LDS at the end (group 1 -> group 0), in a fixed order.
 template <int TN_, int TJ_, int MS>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
+__global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     constexpr int WTN = TN_ / 2, WTJ = TJ_ / 2;
     constexpr int MI = WTN / MS, MJ = WTJ / MS;
     constexpr int ACCN = MS == 32 ? 16 : 4;
@@ -407,7 +415,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     constexpr int STAGE = 2 * (TN_ + TJ_) * ROWB;
     typedef float accv __attribute__((ext_vector_type(ACCN)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;     // position inside the 4-wave group
+    const int grp = threadIdx.x >> 8;                                        // 0: waves 0-3, 1: waves 4-7
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles = g.ntn * g.ntj;
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     int pb_b[4], pb_h[4], pb_w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int pix = chunk0 * 32 + pg * 4 + i;
+        const int pix = (chunk0 + grp) * 32 + pg * 4 + i;
         const int pp = pix < g.M ? pix : (int)p_first;
         const int bb = pp / (g.Ho * g.Wo);
         pb_b[i] = bb - b_first;
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     }
 
     f32x4 ra[4], rb[4];
-    int ld_chunk = 0;
+    int ld_chunk = grp;                                  // this group's chunks: grp, grp + 2, ...
     auto load_chunk = [&]() {
         const int pbase = (chunk0 + ld_chunk) * 32 + pg * 4;
 #pragma unroll
@@ -480,10 +489,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
             const bool ok = bj_ok && pbase + i < g.M && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
             const unsigned off = (unsigned)((pb_b[i] * g.H + hi) * g.W + wi) * x_pix_bytes + (unsigned)jc * 4u;
             rb[i] = y4_buf_load4(x_rsrc, ok ? off : OOB, 0u);
-            pb_w[i] += 32;
+            pb_w[i] += 64;
             while (pb_w[i] >= g.Wo) { pb_w[i] -= g.Wo; if (++pb_h[i] == g.Ho) { pb_h[i] = 0; ++pb_b[i]; } }
         }
-        ++ld_chunk;
+        ld_chunk += 2;
     };
     // split 4 pixels x 4 channels and write the 4 channel rows (2 planes each) transposed
     auto split_store = [&](const f32x4 (&v)[4], const float s, unsigned char* base, int rows) {
@@ -496,8 +505,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
             *reinterpret_cast<u32x2*>(base + rows * ROWB + w_lds[e]) = lo;
         }
     };
-    auto store_chunk = [&](int buf) {
-        unsigned char* as = smem_b + buf * STAGE;
+    auto store_chunk = [&]() {                           // always into this group's own stage
+        unsigned char* as = smem_b + grp * STAGE;
         if (a_act) split_store(ra, s_dy, as, TN_);
         if (b_act) split_store(rb, s_x, as + 2 * TN_ * ROWB, TJ_);
     };
@@ -563,20 +572,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
         }
     };
 
-    if (nchunks > 0) {
-        load_chunk();
-        store_chunk(0);
-        if (nchunks > 1) load_chunk();
-        __syncthreads();
-        for (int ch = 0; ch < nchunks; ++ch) {
-            if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
-            if (ch + 2 < nchunks) load_chunk();
-            compute(ch & 1);
-            __syncthreads();
+    // phase p: group p & 1 computes chunk p; the other group writes chunk p + 1 into its stage and loads chunk p + 3
+    if (grp < nchunks) load_chunk();                     // chunk grp
+    if (grp == 0 && nchunks > 0) {
+        store_chunk();
+        if (2 < nchunks) load_chunk();                   // chunk 2
+    }
+    __syncthreads();
+    for (int ph = 0; ph < nchunks; ++ph) {
+        if ((ph & 1) == grp) {
+            compute(grp);
+        } else {
+            if (ph + 1 < nchunks) store_chunk();
+            if (ph + 3 < nchunks) load_chunk();
         }
+        __syncthreads();
     }
     const float un = f16x2_unscale(g.dy_amax) * f16x2_unscale(g.x_amax);
     const float un1 = un * (1.0f / 2048.0f);
+    // group 1 hands its partial tile to group 0 through LDS (slot = element * 256 + thread: conflict-free, and both
+    // groups use the same thread -> element map); the loop ended with a barrier, the stages are free
+    float* xch = reinterpret_cast<float*>(smem_b);
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int jj = 0; jj < MJ; ++jj)
+#pragma unroll
+                for (int e = 0; e < ACCN; ++e)
+                    xch[((i * MJ + jj) * ACCN + e) * 256 + tid] = acc0[i][jj][e] * un + acc1[i][jj][e] * un1;
+    }
+    __syncthreads();
+    if (grp == 1) return;
     float* out = g.out + (long long)split * g.Cout * g.J;
 #pragma unroll
     for (int jj = 0; jj < MJ; ++jj) {
@@ -587,7 +614,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
                 const int n = nb + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
-                if (n < g.Cout && jcol < g.J) out[(long long)n * g.J + jcol] = acc0[i][jj][e] * un + acc1[i][jj][e] * un1;
+                const float v = (acc0[i][jj][e] * un + acc1[i][jj][e] * un1) + xch[((i * MJ + jj) * ACCN + e) * 256 + tid];
+                if (n < g.Cout && jcol < g.J) out[(long long)n * g.J + jcol] = v;
             }
         }
     }
@@ -1277,7 +1305,9 @@ int dispatch_gather_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
 
 template <int TN_, int TJ_, int MS>
 int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
-    const size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;
+    size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;                        // two stages (one per wave group)
+    const size_t xch = (size_t)(TN_ / 2) * (TJ_ / 2) / 64 * 256 * sizeof(float);   // partial-tile exchange: per-thread elements x 256
+    if (smem < xch) smem = xch;
     auto kern = conv_wgrad_f16x2<TN_, TJ_, MS>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1285,7 +1315,7 @@ int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(512), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -442,6 +442,9 @@ def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None):
             ready()
     x.record_stream(side)
     dy.record_stream(side)
+    for cell in (x_amax, dy_amax):                   # operand maxima are read by the side-stream kernel as well
+        if cell is not None:
+            cell.record_stream(side)
     if not _ASYNC['join_queued']:
         _ASYNC['join_queued'] = True
         torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
