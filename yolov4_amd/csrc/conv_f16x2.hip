@@ -45,16 +45,39 @@ __device__ __forceinline__ float f16x2_unscale(const unsigned* amax) {
     return __uint_as_float((254u - f16x2_scale_exp(amax ? *amax : 0u)) << 23);
 }
 
-// 4 consecutive fp32 values -> 4 hi halfs (hi[0..1]) and 4 scaled lo halfs
+// 4 consecutive fp32 values -> 4 hi halfs (hi[0..1]) and 4 scaled lo halfs.
+// Y4_SPLIT_ASM (default): 3 VALU per element on the mixed-precision fma unit -- v_fma_mixlo/mixhi_f16 scale, round (RN)
+// and pack in one instruction each, v_fma_mix_f32 forms x s - hi exactly with the fp16 half as an operand -- instead of
+// the 3.5 the compiler emits from the portable source, two of them packed-fp32 ops that issue slowly beside MFMAs.
+#ifndef Y4_SPLIT_ASM
+#define Y4_SPLIT_ASM 1
+#endif
+__device__ __forceinline__ void split2_pair(const float x0, const float x1, const float s, unsigned& hi, unsigned& lo) {
+#if Y4_SPLIT_ASM
+    unsigned h, l;
+    float r0, r1;
+    asm("v_fma_mixlo_f16 %0, %4, %6, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %5, %6, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mix_f32 %2, %4, %6, -%0 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mix_f32 %3, %5, %6, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %2, %7, 0 op_sel_hi:[0,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %7, 0 op_sel_hi:[0,0,0]"
+        : "=&v"(h), "=&v"(l), "=&v"(r0), "=&v"(r1)
+        : "v"(x0), "v"(x1), "v"(s), "v"(2048.0f));
+    hi = h; lo = l;
+#else
+    f16x2v h, l;
+    const float t0 = x0 * s, t1 = x1 * s;
+    h[0] = (_Float16)t0; h[1] = (_Float16)t1;
+    l[0] = (_Float16)((t0 - (float)h[0]) * 2048.f); l[1] = (_Float16)((t1 - (float)h[1]) * 2048.f);
+    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
+#endif
+}
 __device__ __forceinline__ void split2x4(const f32x4 v, const float s, u32x2& hi, u32x2& lo) {
-    f16x2v h01, h23, l01, l23;
-    const float x0 = v[0] * s, x1 = v[1] * s, x2 = v[2] * s, x3 = v[3] * s;
-    h01[0] = (_Float16)x0; h01[1] = (_Float16)x1; h23[0] = (_Float16)x2; h23[1] = (_Float16)x3;
-    const float r0 = x0 - (float)h01[0], r1 = x1 - (float)h01[1], r2 = x2 - (float)h23[0], r3 = x3 - (float)h23[1];
-    l01[0] = (_Float16)(r0 * 2048.f); l01[1] = (_Float16)(r1 * 2048.f);
-    l23[0] = (_Float16)(r2 * 2048.f); l23[1] = (_Float16)(r3 * 2048.f);
-    hi[0] = __builtin_bit_cast(unsigned, h01); hi[1] = __builtin_bit_cast(unsigned, h23);
-    lo[0] = __builtin_bit_cast(unsigned, l01); lo[1] = __builtin_bit_cast(unsigned, l23);
+    unsigned h0, l0, h1, l1;
+    split2_pair(v[0], v[1], s, h0, l0);
+    split2_pair(v[2], v[3], s, h1, l1);
+    hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
 }
 __device__ __forceinline__ void split2(const float x, const float s, unsigned short& hi, unsigned short& lo) {
     const float xs = x * s;
@@ -398,16 +421,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
 // D[n][j] = sum_p dy[p][n] * xg[p][j]; both operands transposed into LDS as [n or j][32 pixels] rows while being
 // split: each thread owns one 4-pixel x 4-channel block of each operand per 32-pixel chunk (4 coalesced 16-B loads,
 // a 4x4 register transpose folded into the fp16 packing, 8 ds_write_b64).
-//
-// Ping-pong: ONE 8-wave block per CU.  Waves 0-3 ("group 0") and waves 4-7 ("group 1") -- wave w and w + 4 share a
-// SIMD -- both own the WHOLE output tile and take alternate 32-pixel chunks; while one group runs the 48 MFMAs of
-// its chunk out of its LDS stage, the other splits and writes its next chunk into the other stage and issues the
-// global loads of the one after (two phases of flight time).  One barrier per phase.  Two independent 4-wave blocks
-// per CU ran in lockstep instead (matrix phases coincided, then both staged: PMC MFMA-busy 0.31); here the matrix
-// pipe of every SIMD always has a wave feeding it while its partner does the VALU / LDS-write work.  The two partial
-// tiles are added through LDS at the end (group 1 -> group 0), in a fixed order.
+// (Measured and dropped: an 8-wave "ping-pong" form -- one block per CU, two 4-wave groups taking alternate chunks, one
+// staging while the other runs its MFMAs -- was 1.5x SLOWER (64.8 vs 42.4 ms per step over all wgrad launches): the
+// kernel is bound by the VALU work of the operand split, and a ping-pong lets only half the waves do VALU at a time.)
 template <int TN_, int TJ_, int MS>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     constexpr int WTN = TN_ / 2, WTJ = TJ_ / 2;
     constexpr int MI = WTN / MS, MJ = WTJ / MS;
     constexpr int ACCN = MS == 32 ? 16 : 4;
@@ -415,8 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     constexpr int STAGE = 2 * (TN_ + TJ_) * ROWB;
     typedef float accv __attribute__((ext_vector_type(ACCN)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;     // position inside the 4-wave group
-    const int grp = threadIdx.x >> 8;                                        // 0: waves 0-3, 1: waves 4-7
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles = g.ntn * g.ntj;
@@ -454,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     int pb_b[4], pb_h[4], pb_w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int pix = (chunk0 + grp) * 32 + pg * 4 + i;
+        const int pix = chunk0 * 32 + pg * 4 + i;
         const int pp = pix < g.M ? pix : (int)p_first;
         const int bb = pp / (g.Ho * g.Wo);
         pb_b[i] = bb - b_first;
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     }
 
     f32x4 ra[4], rb[4];
-    int ld_chunk = grp;                                  // this group's chunks: grp, grp + 2, ...
+    int ld_chunk = 0;
     auto load_chunk = [&]() {
         const int pbase = (chunk0 + ld_chunk) * 32 + pg * 4;
 #pragma unroll
@@ -489,10 +506,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
             const bool ok = bj_ok && pbase + i < g.M && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
             const unsigned off = (unsigned)((pb_b[i] * g.H + hi) * g.W + wi) * x_pix_bytes + (unsigned)jc * 4u;
             rb[i] = y4_buf_load4(x_rsrc, ok ? off : OOB, 0u);
-            pb_w[i] += 64;
+            pb_w[i] += 32;
             while (pb_w[i] >= g.Wo) { pb_w[i] -= g.Wo; if (++pb_h[i] == g.Ho) { pb_h[i] = 0; ++pb_b[i]; } }
         }
-        ld_chunk += 2;
+        ++ld_chunk;
     };
     // split 4 pixels x 4 channels and write the 4 channel rows (2 planes each) transposed
     auto split_store = [&](const f32x4 (&v)[4], const float s, unsigned char* base, int rows) {
@@ -505,8 +522,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
             *reinterpret_cast<u32x2*>(base + rows * ROWB + w_lds[e]) = lo;
         }
     };
-    auto store_chunk = [&]() {                           // always into this group's own stage
-        unsigned char* as = smem_b + grp * STAGE;
+    auto store_chunk = [&](int buf) {
+        unsigned char* as = smem_b + buf * STAGE;
         if (a_act) split_store(ra, s_dy, as, TN_);
         if (b_act) split_store(rb, s_x, as + 2 * TN_ * ROWB, TJ_);
     };
@@ -572,38 +589,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
         }
     };
 
-    // phase p: group p & 1 computes chunk p; the other group writes chunk p + 1 into its stage and loads chunk p + 3
-    if (grp < nchunks) load_chunk();                     // chunk grp
-    if (grp == 0 && nchunks > 0) {
-        store_chunk();
-        if (2 < nchunks) load_chunk();                   // chunk 2
-    }
-    __syncthreads();
-    for (int ph = 0; ph < nchunks; ++ph) {
-        if ((ph & 1) == grp) {
-            compute(grp);
-        } else {
-            if (ph + 1 < nchunks) store_chunk();
-            if (ph + 3 < nchunks) load_chunk();
-        }
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+        if (nchunks > 1) load_chunk();
         __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+            if (ch + 2 < nchunks) load_chunk();
+            compute(ch & 1);
+            __syncthreads();
+        }
     }
     const float un = f16x2_unscale(g.dy_amax) * f16x2_unscale(g.x_amax);
     const float un1 = un * (1.0f / 2048.0f);
-    // group 1 hands its partial tile to group 0 through LDS (slot = element * 256 + thread: conflict-free, and both
-    // groups use the same thread -> element map); the loop ended with a barrier, the stages are free
-    float* xch = reinterpret_cast<float*>(smem_b);
-    if (grp == 1) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int jj = 0; jj < MJ; ++jj)
-#pragma unroll
-                for (int e = 0; e < ACCN; ++e)
-                    xch[((i * MJ + jj) * ACCN + e) * 256 + tid] = acc0[i][jj][e] * un + acc1[i][jj][e] * un1;
-    }
-    __syncthreads();
-    if (grp == 1) return;
     float* out = g.out + (long long)split * g.Cout * g.J;
 #pragma unroll
     for (int jj = 0; jj < MJ; ++jj) {
@@ -614,8 +613,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_f16x2(const WgradGeom g) {
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
                 const int n = nb + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
-                const float v = (acc0[i][jj][e] * un + acc1[i][jj][e] * un1) + xch[((i * MJ + jj) * ACCN + e) * 256 + tid];
-                if (n < g.Cout && jcol < g.J) out[(long long)n * g.J + jcol] = v;
+                if (n < g.Cout && jcol < g.J) out[(long long)n * g.J + jcol] = acc0[i][jj][e] * un + acc1[i][jj][e] * un1;
             }
         }
     }
@@ -1305,9 +1303,7 @@ int dispatch_gather_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
 
 template <int TN_, int TJ_, int MS>
 int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
-    size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;                        // two stages (one per wave group)
-    const size_t xch = (size_t)(TN_ / 2) * (TJ_ / 2) / 64 * 256 * sizeof(float);   // partial-tile exchange: per-thread elements x 256
-    if (smem < xch) smem = xch;
+    const size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;
     auto kern = conv_wgrad_f16x2<TN_, TJ_, MS>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1315,7 +1311,7 @@ int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(512), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -1368,7 +1368,6 @@ void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int stride, Wgrad
     int per_cu = (160 * 1024) / (2 * 32 * (g.tn + g.tj) * 4);
     if (per_cu > 4) per_cu = 4;
     if (g.tn + g.tj == 256 && per_cu > 2) per_cu = 2;      // 128x128: 124 VGPRs + 64 KiB
-    if (g_conv_mode == 3) per_cu = (g.tn + g.tj == 256) ? 1 : 2;   // f16x2: 8-wave ping-pong blocks (240 VGPRs at 128x128)
     const int slots = 256 * per_cu;
     // choose the split count in [1, chunks/16] that fills whole rounds of `slots` blocks best
     int max_s = chunks / 16;
