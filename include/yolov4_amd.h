@@ -125,6 +125,8 @@ size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k);
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes, const unsigned* dy_amax /* mode 3, nullable */,
+                        int dy_is_planes /* mode 3: dy was written by y4_bn_act_bwd_f32(f16_planes) -- per pixel [Cout hi
+                           halfs][Cout lo halfs]; needs dy_amax = its word [5], lddy == Cout, Cout % 32 == 0 */,
                         const float* residual, int ldr, void* stream);
 
 /* wgrad: dw[Cout][k][k][Cin] = sum_{b,ho,wo} dy (x) x -- autograd of nn.Conv2d wrt weight.
@@ -133,7 +135,8 @@ size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, 
 int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes,
-                        const unsigned* x_amax, const unsigned* dy_amax /* mode 3, nullable */, void* stream);
+                        const unsigned* x_amax, const unsigned* dy_amax /* mode 3, nullable */,
+                        int dy_is_planes /* as y4_conv2d_dgrad_f32 */, void* stream);
 size_t y4_conv2d_stem_wgrad_workspace(int B, int H, int W, int Cout);
 int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
                              const float* dy, int lddy, float* dw, int B, int H, int W, int Cout,
@@ -175,7 +178,13 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,
                       long long M, int C, void* workspace, size_t workspace_bytes,
-                      unsigned* out_amax /* nullable: max|finite dy|, as above */, void* stream);
+                      unsigned* out_amax /* nullable: max|finite dy|, as above */,
+                      unsigned* f16_planes /* nullable, 8 zeroed device words, conv mode 3: dy is written as the two fp16
+                         pieces of the f16x2 split -- per pixel [C hi halfs][C scaled-lo halfs] in the 4C bytes of its
+                         row (lddy == C, C % 32 == 0) -- scaled by a bound of max|dy| derived before the sweep; word [5]
+                         receives that bound and serves as dy_amax of y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 with
+                         dy_is_planes = 1 */,
+                      void* stream);
 /* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249). workspace: C doubles */
 int y4_bias_grad_f32(const float* dy, int lddy, long long M, int C, float* dbias,
                      void* workspace, size_t workspace_bytes, void* stream);

@@ -20,6 +20,10 @@
 #include "common.h"
 #include "conv_geom.h"
 
+#ifndef Y4_STAMPS
+#define Y4_STAMPS 0
+#endif
+
 namespace {
 
 using y4::ConvGeom;
@@ -46,11 +50,13 @@ __device__ __forceinline__ float f16x2_unscale(const unsigned* amax) {
 }
 
 // 4 consecutive fp32 values -> 4 hi halfs (hi[0..1]) and 4 scaled lo halfs.
-// Y4_SPLIT_ASM (default): 3 VALU per element on the mixed-precision fma unit -- v_fma_mixlo/mixhi_f16 scale, round (RN)
-// and pack in one instruction each, v_fma_mix_f32 forms x s - hi exactly with the fp16 half as an operand -- instead of
-// the 3.5 the compiler emits from the portable source, two of them packed-fp32 ops that issue slowly beside MFMAs.
+// Y4_SPLIT_ASM=1 (off by default) replaces the compiler's 3.5 VALU per element (two of them packed-fp32 ops) by 3 on the
+// mixed-precision fma unit (v_fma_mixlo/mixhi_f16 scale + round + pack in one instruction, v_fma_mix_f32 forms x s - hi
+// with the fp16 half as an operand).  Measured A/B on one box, whole step: 357-359 img/s with it, 360 without -- the
+// split VALU is not what bounds these kernels -- and fragments that go from the asm block straight into an MFMA (the
+// streaming 1x1 kernel) would need manual wait states (hipcc pads nothing after inline asm).  Kept for the record.
 #ifndef Y4_SPLIT_ASM
-#define Y4_SPLIT_ASM 1
+#define Y4_SPLIT_ASM 0
 #endif
 __device__ __forceinline__ void split2_pair(const float x0, const float x1, const float s, unsigned& hi, unsigned& lo) {
 #if Y4_SPLIT_ASM
@@ -104,10 +110,12 @@ constexpr int ROWB = 64;                                   // bytes per LDS row 
 // ==================================================================================== forward / dgrad
 // TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
 // TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
-template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int MS>
+// APL: the gathered tensor arrives pre-split (ConvGeom::src_planes: dy planes written by the BatchNorm backward sweep);
+//      its tile is then staged like the filter tile -- 16-B loads of each plane, ds_write_b128, no VALU.
+template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int MS, bool APL = false>
 __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     constexpr int BK = 32;
-    constexpr int PA = BM / 32;
+    constexpr int PA = APL ? (BM * 4 + 255) / 256 : BM / 32;   // A items per thread: 16-B plane chunks, or fp32 row chunks
     constexpr int NB = (BN * 4 + 255) / 256;               // 16-B chunks of the B tile per thread and plane
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MS, TN = WTN / MS;
@@ -163,29 +171,31 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int row = p * 32 + lrow;
+        const int row = APL ? (tid + 256 * p) >> 2 : p * 32 + lrow;
         const int i = mt_local * BM + row;
         int b, hd, wd;
         if (!classed) {
-            a_ok[p] = i < g.M;
+            a_ok[p] = i < g.M && row < BM;
             const int ii = a_ok[p] ? i : 0;
             b = ii / (g.Hd * g.Wd);
             const int rem = ii - b * (g.Hd * g.Wd);
             hd = rem / g.Wd; wd = rem - hd * g.Wd;
         } else {
             const int hc = g.cls_h[ph], wc = g.cls_w[pw];
-            a_ok[p] = i < g.B * hc * wc;
+            a_ok[p] = i < g.B * hc * wc && row < BM;
             const int ii = a_ok[p] ? i : 0;
             b = ii / (hc * wc);
             const int rem = ii - b * (hc * wc);
             const int hh = rem / wc;
             hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
         }
-        if (kc == 0) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
-        a_base[p] = (unsigned)(b - b_first) * (unsigned)(g.Hs * g.Ws) * pix_bytes + kc * 16u;
+        const int ach = APL ? ((tid + 256 * p) & 3) : kc;                      // 16-B chunk inside the K-tile row
+        if (ach == 0 && row < BM) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
+        a_base[p] = (unsigned)(b - b_first) * (unsigned)(g.Hs * g.Ws) * pix_bytes + ach * 16u;
         if (!TRANSPOSED) { a_h[p] = hd * g.stride - g.pad; a_w[p] = wd * g.stride - g.pad; }
         else { a_h[p] = hd + g.pad; a_w[p] = wd + g.pad; }
-        a_lds[p] = row * ROWB + (((kc >> 1) ^ lds_swz<MS>(row)) << 4) + ((kc & 1) << 3);
+        if (APL) a_lds[p] = row < BM ? row * ROWB + ((ach ^ lds_swz<MS>(row)) << 4) : -1;
+        else a_lds[p] = row * ROWB + (((kc >> 1) ^ lds_swz<MS>(row)) << 4) + ((kc & 1) << 3);
     }
     unsigned b_off[NB];
     int b_lds[NB];
@@ -199,9 +209,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         b_lds[i] = row < BN ? row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
     }
 
-    f32x4 ra[PA];
+    f32x4 ra[APL ? 1 : PA];
+    u32x4 rap[APL ? PA : 1][2];                            // APL: hi / lo plane chunks
     u32x4 rb[NB][2];
     const int CC = g.Cs / BK;
+    const unsigned a_lo = (unsigned)g.Cs * 2u;             // APL: byte offset of the lo plane inside a pixel row
     int r = r0, q = q0, cc = 0;
     unsigned a_off[PA];
     auto tap_setup = [&]() {
@@ -223,8 +235,16 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     };
     tap_setup();
     auto load_tile = [&]() {
+        if constexpr (APL) {
 #pragma unroll
-        for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
+            for (int p = 0; p < PA; ++p) {
+                rap[p][0] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u), 0);
+                rap[p][1] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u + a_lo), 0);
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
+        }
         const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 2u);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
@@ -237,6 +257,14 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     auto store_tile = [&](int buf) {
         unsigned char* as = smem_b + buf * STAGE;
         unsigned char* bs = as + 2 * BM * ROWB;
+        if constexpr (APL) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p)
+                if (a_lds[p] >= 0) {
+                    *reinterpret_cast<u32x4*>(as + a_lds[p]) = rap[p][0];
+                    *reinterpret_cast<u32x4*>(as + BM * ROWB + a_lds[p]) = rap[p][1];
+                }
+        } else
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             f32x4 v = ra[p];
@@ -328,12 +356,36 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     store_tile(0);
     if (KT > 1) load_tile();
     __syncthreads();
+#if Y4_STAMPS
+    // diagnostic build only (never shipped): where one K-tile iteration of a wave spends its cycles
+    unsigned long long t_store = 0, t_load = 0, t_comp = 0, t_bar = 0;
+#define Y4_T(x) { __builtin_amdgcn_sched_barrier(0); x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+    for (int kt = 0; kt < KT; ++kt) {
+        unsigned long long a0, a1, a2, a3, a4;
+        Y4_T(a0);
+        if (kt + 1 < KT) store_tile((kt + 1) & 1);
+        Y4_T(a1);
+        if (kt + 2 < KT) load_tile();
+        Y4_T(a2);
+        compute(kt & 1);
+        asm volatile("s_nop 0" ::: "memory");
+        Y4_T(a3);
+        __syncthreads();
+        Y4_T(a4);
+        t_store += a1 - a0; t_load += a2 - a1; t_comp += a3 - a2; t_bar += a4 - a3;
+    }
+    if (lane == 0 && g.stamps) {
+        atomicAdd(g.stamps + 0, t_store); atomicAdd(g.stamps + 1, t_load); atomicAdd(g.stamps + 2, t_comp);
+        atomicAdd(g.stamps + 3, t_bar); atomicAdd(g.stamps + 4, (unsigned long long)KT);
+    }
+#else
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) store_tile((kt + 1) & 1);         // split + write the prefetched tile into the other stage
         if (kt + 2 < KT) load_tile();                      // its successor's loads fly under this tile's MFMAs
         compute(kt & 1);
         __syncthreads();
     }
+#endif
 
     // ---- epilogue: c = (acc0 + 2^-11 acc1) / (s_A s_B); element (row, col) of a tile:
     //   32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);   16x16: col = lane & 15, row = 4 (lane >> 4) + e
@@ -424,7 +476,9 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
 // (Measured and dropped: an 8-wave "ping-pong" form -- one block per CU, two 4-wave groups taking alternate chunks, one
 // staging while the other runs its MFMAs -- was 1.5x SLOWER (64.8 vs 42.4 ms per step over all wgrad launches): the
 // kernel is bound by the VALU work of the operand split, and a ping-pong lets only half the waves do VALU at a time.)
-template <int TN_, int TJ_, int MS>
+// APL: dy arrives pre-split (WgradGeom::dy_planes): threads 0-127 take the hi plane, 128-255 the lo plane; each owns a
+//      4-pixel x 8-channel block (4 x 16-B loads), transposes it with 16 v_perm_b32 and writes 8 channel rows of 8 B.
+template <int TN_, int TJ_, int MS, bool APL = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     constexpr int WTN = TN_ / 2, WTJ = TJ_ / 2;
     constexpr int MI = WTN / MS, MJ = WTJ / MS;
@@ -491,10 +545,28 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
         w_lds[e] = row * ROWB + (((pg >> 1) ^ lds_swz<MS>(row)) << 4) + ((pg & 1) << 3);
     }
 
+    // APL staging map of dy: plane, 4-pixel group, 8-channel group
+    const int apl = tid >> 7, apg = tid & 7, acg = (tid & 127) >> 3;
+    const bool ap_ok = APL && acg * 8 < TN_ && (n0 + acg * 8) < g.Cout;
+    const unsigned ap_off0 = ap_ok ? (unsigned)(apg * 4) * dy_pix_bytes + (unsigned)apl * (unsigned)g.Cout * 2u + (unsigned)(n0 + acg * 8) * 2u : OOB;
+    int ap_lds[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int row = acg * 8 + c;
+        ap_lds[c] = apl * TN_ * ROWB + row * ROWB + (((apg >> 1) ^ lds_swz<MS>(row)) << 4) + ((apg & 1) << 3);
+    }
     f32x4 ra[4], rb[4];
     int ld_chunk = 0;
     auto load_chunk = [&]() {
         const int pbase = (chunk0 + ld_chunk) * 32 + pg * 4;
+        if constexpr (APL) {
+            const int pb2 = (chunk0 + ld_chunk) * 32 + apg * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = ap_ok && pb2 + i < g.M;
+                ra[i] = y4_buf_load4(dy_rsrc, ok ? ap_off0 + (unsigned)i * dy_pix_bytes : OOB, (unsigned)ld_chunk * chunk_bytes);
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = an_ok && pbase + i < g.M;
@@ -524,7 +596,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     };
     auto store_chunk = [&](int buf) {
         unsigned char* as = smem_b + buf * STAGE;
-        if (a_act) split_store(ra, s_dy, as, TN_);
+        if constexpr (APL) {
+            if (acg * 8 < TN_) {
+                // ra[i] = 8 halfs (channels c0..c0+7) of pixel i; row c gets {px0, px1, px2, px3} of channel c
+                u32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(u32x4, ra[i]);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;      // upper / lower half of both dwords
+                    u32x2 o;
+                    o[0] = __builtin_amdgcn_perm(v[1][c >> 1], v[0][c >> 1], sel);
+                    o[1] = __builtin_amdgcn_perm(v[3][c >> 1], v[2][c >> 1], sel);
+                    *reinterpret_cast<u32x2*>(as + ap_lds[c]) = o;
+                }
+            }
+        } else {
+            if (a_act) split_store(ra, s_dy, as, TN_);
+        }
         if (b_act) split_store(rb, s_x, as + 2 * TN_ * ROWB, TJ_);
     };
 
@@ -634,14 +723,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
 //   * per 9 taps a thread issues <= 10 activation loads and splits <= 40 values instead of 36 loads / 144 values.
 constexpr int HALO_ROWS = 304;                             // patch capacity (rows of 32 channels)
 
-template <int BN, bool TRANSPOSED, int MS>
+template <int BN, bool TRANSPOSED, int MS, bool APL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, const int tiles_per_img) {
     constexpr int BM = 128, WM = 2, WN = 2;
     constexpr int NB = (BN * 4 + 255) / 256;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MS, TN = WTN / MS;
     constexpr int ACCN = MS == 32 ? 16 : 4;
-    constexpr int PP = (HALO_ROWS + 31) / 32;              // patch rows per thread (32 rows x 8 chunks per pass)
+    constexpr int PP = APL ? (HALO_ROWS + 63) / 64 : (HALO_ROWS + 31) / 32;   // patch items per thread (plane: 64 rows x 4 chunks per pass)
     constexpr int PATCH = 2 * HALO_ROWS * ROWB;            // bytes: 2 planes
     constexpr int BSTAGE = 2 * BN * ROWB;                  // bytes per filter stage: 2 planes
     typedef float accv __attribute__((ext_vector_type(ACCN)));
@@ -678,12 +767,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
     int a_lds[PP];
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
-        const int j = p * 32 + lrow;
+        const int j = APL ? p * 64 + (tid >> 2) : p * 32 + lrow;
+        const int ach = APL ? (tid & 3) : kc;
         const int pf = p_lo + j;
         const int hp = pf / Wp, wp = pf - hp * Wp;
         const bool ok = j < prow_n && hp >= 1 && hp <= H && wp >= 1 && wp <= W;
-        a_off[p] = ok ? (unsigned)((hp - 1) * W + (wp - 1)) * pix_bytes + kc * 16u : OOB;
-        a_lds[p] = j < HALO_ROWS ? j * ROWB + (((kc >> 1) ^ lds_swz<MS>(j)) << 4) + ((kc & 1) << 3) : -1;
+        a_off[p] = ok ? (unsigned)((hp - 1) * W + (wp - 1)) * pix_bytes + ach * 16u : OOB;
+        if (APL) a_lds[p] = j < HALO_ROWS ? j * ROWB + ((ach ^ lds_swz<MS>(j)) << 4) : -1;
+        else a_lds[p] = j < HALO_ROWS ? j * ROWB + (((kc >> 1) ^ lds_swz<MS>(j)) << 4) + ((kc & 1) << 3) : -1;
     }
     // ---- filter chunks of this thread
     unsigned b_off[NB];
@@ -721,6 +812,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
             }
     };
     auto stage_patch = [&](int cc) {
+        if constexpr (APL) {
+            u32x4 rp[PP][2];
+            const unsigned a_lo = (unsigned)g.Cs * 2u;
+#pragma unroll
+            for (int p = 0; p < PP; ++p) {
+                rp[p][0] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u), 0);
+                rp[p][1] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u + a_lo), 0);
+            }
+#pragma unroll
+            for (int p = 0; p < PP; ++p)
+                if (a_lds[p] >= 0) {
+                    *reinterpret_cast<u32x4*>(smem_b + a_lds[p]) = rp[p][0];
+                    *reinterpret_cast<u32x4*>(smem_b + HALO_ROWS * ROWB + a_lds[p]) = rp[p][1];
+                }
+            return;
+        }
         f32x4 ra[PP];
 #pragma unroll
         for (int p = 0; p < PP; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)cc * 128u);
@@ -914,7 +1021,7 @@ bool halo_ok(const ConvGeom& g) {
     return halo_patch_rows(g.Hs, g.Ws) <= HALO_ROWS;
 }
 
-template <bool TR, int MS>
+template <bool TR, int MS, bool APL = false>
 int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     constexpr int BN = 128;
     ConvGeom g = g0;
@@ -925,7 +1032,7 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
     if (nparts) *nparts = g.mtiles;
     const size_t smem = 2ull * HALO_ROWS * ROWB + 2ull * 2 * BN * ROWB;
-    auto kern = conv3x3_halo_f16x2<BN, TR, MS>;
+    auto kern = conv3x3_halo_f16x2<BN, TR, MS, APL>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -942,7 +1049,7 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
 // stays in LDS for the life of a persistent block and every wave streams its own 32 pixel rows from global memory
 // straight into the MFMA A-operand layout (lane = pixel, 8 consecutive channels = 32 contiguous bytes), splits them
 // in registers and never meets a barrier; the next tile's loads fly under this tile's MFMAs / stores.
-template <int KS, int NT, int NW = 4>
+template <int KS, int NT, int NW = 4, bool APL = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2(const ConvGeom g) {
     constexpr int NTHR = NW * 64, TROWS = NW * 32;
     constexpr int K = KS * 16;
@@ -972,9 +1079,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
     const float un = f16x2_unscale(g.src_amax) * f16x2_unscale(g.wt_amax);
     const float un1 = un * (1.0f / 2048.0f);
     constexpr int KH = KS == 8 ? 4 : KS;
-    f32x4 ra0[KH][2], ra1[KH][2];
+    f32x4 ra0[KH][2], ra1[KH][2];                         // APL: [ks][0] = hi fragment, [ks][1] = lo fragment (bit patterns)
     auto load = [&](f32x4 (&ra)[KH][2], int tile, int ks0) {
         const int m = tile * TROWS + wave * 32 + fr;
+        if constexpr (APL) {
+            // pre-split source: lane (pixel fr, k half fh) takes 8 consecutive channels = 16 B of each plane
+            const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 16u : 0xffffffffu;
+#pragma unroll
+            for (int ks = 0; ks < KH; ++ks) {
+                ra[ks][0] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 32u);
+                ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 32u + (unsigned)K * 2u);
+            }
+            return;
+        }
         const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 32u : 0xffffffffu;
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
@@ -1003,11 +1120,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         if constexpr (KS == 8) asm volatile("" ::: "memory");      // re-read the filter fragments per tile (no spills)
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
-            u32x2 h0, l0, h1, l1;
-            split2x4(ra[ks][0], sa, h0, l0);
-            split2x4(ra[ks][1], sa, h1, l1);
-            const u32x4 qh = {h0[0], h0[1], h1[0], h1[1]}, ql = {l0[0], l0[1], l1[0], l1[1]};
-            const f16x8 fah = __builtin_bit_cast(f16x8, qh), fal = __builtin_bit_cast(f16x8, ql);
+            f16x8 fah, fal;
+            if constexpr (APL) {
+                fah = __builtin_bit_cast(f16x8, ra[ks][0]);
+                fal = __builtin_bit_cast(f16x8, ra[ks][1]);
+            } else {
+                u32x2 h0, l0, h1, l1;
+                split2x4(ra[ks][0], sa, h0, l0);
+                split2x4(ra[ks][1], sa, h1, l1);
+                const u32x4 qh = {h0[0], h0[1], h1[0], h1[1]}, ql = {l0[0], l0[1], l1[0], l1[1]};
+                fah = __builtin_bit_cast(f16x8, qh);
+                fal = __builtin_bit_cast(f16x8, ql);
+            }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const f16x8 fbh = *reinterpret_cast<const f16x8*>(b_frag + (j * 32) * PITCH + (ks0 + ks) * 32);
@@ -1097,8 +1221,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
     }
 }
 
+template <int KS, int NT, int NW, bool APL>
+int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts);
 template <int KS, int NT, int NW = 4>
 int launch_stream1x1_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
+    if (g0.src_planes) return launch_stream1x1_f16x2_impl<KS, NT, NW, true>(g0, st, nparts);
+    return launch_stream1x1_f16x2_impl<KS, NT, NW, false>(g0, st, nparts);
+}
+template <int KS, int NT, int NW, bool APL>
+int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts) {
     ConvGeom g = g0;
     g.mtiles = (g.M + NW * 32 - 1) / (NW * 32);
     g.ntiles = 1;
@@ -1106,7 +1237,7 @@ int launch_stream1x1_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     size_t smem = (size_t)2 * NT * 32 * (KS * 32 + 16);
     const size_t red = (size_t)NW * NT * 32 * 2 * sizeof(float);
     if (smem < red) smem = red;
-    auto kern = conv1x1_stream_f16x2<KS, NT, NW>;
+    auto kern = conv1x1_stream_f16x2<KS, NT, NW, APL>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1231,7 +1362,7 @@ __global__ void amax_merge_kernel(unsigned* __restrict__ dst, const unsigned* __
 
 int g_f16x2_shape = 16;          // MFMA shape of the f16x2 kernels: 32 (32x32x16) or 16 (16x16x32); Y4_F16X2_SHAPE overrides
 
-template <int BM, int BN, int WM, int WN, bool TR, int MS>
+template <int BM, int BN, int WM, int WN, bool TR, int MS, bool APL = false>
 int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
     ConvGeom g = g0;
     if (TR && g.stride == 2) {
@@ -1261,7 +1392,7 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
         g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
     }
     const size_t smem = 2ull * 2 * (BM + BN) * ROWB + BM * sizeof(int);
-    auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS>;
+    auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS, APL>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1286,6 +1417,21 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
 template <bool TR, int MS>
 int dispatch_gather_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
     if (nparts) *nparts = (g.M + 127) / 128;
+    if constexpr (TR) {
+        if (g.src_planes) {                                // dgrad of a BatchNorm layer: dy arrives as planes
+            if (g.Cs_valid != g.Cs) return Y4_ERR_SHAPE;
+            if (g.N > 64) {
+                const long long nt = (g.N + 127) / 128;
+                const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
+                const double c128 = (double)((b128 + 511) / 512) * 128.0;
+                const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.10;
+                if (c64 < c128 && g.stride != 2) return launch_gather_f16x2<64, 128, 2, 2, TR, MS, true>(g, st);
+                return launch_gather_f16x2<128, 128, 2, 2, TR, MS, true>(g, st);
+            }
+            if (g.N > 32) return launch_gather_f16x2<128, 64, 2, 2, TR, MS, true>(g, st);
+            return launch_gather_f16x2<128, 32, 4, 1, TR, MS, true>(g, st);
+        }
+    }
     if (g.N > 64) {
         const long long nt = (g.N + 127) / 128;
         const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
@@ -1301,10 +1447,10 @@ int dispatch_gather_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
     return launch_gather_f16x2<128, 32, 4, 1, TR, MS>(g, st);
 }
 
-template <int TN_, int TJ_, int MS>
-int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
+template <int TN_, int TJ_, int MS, bool APL>
+int launch_wgrad_f16x2_impl(const WgradGeom& g, hipStream_t st) {
     const size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;
-    auto kern = conv_wgrad_f16x2<TN_, TJ_, MS>;
+    auto kern = conv_wgrad_f16x2<TN_, TJ_, MS, APL>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1314,6 +1460,15 @@ int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
+}
+
+template <int TN_, int TJ_, int MS>
+int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
+    if (g.dy_planes) {
+        if (g.Cout % 32 != 0 || g.lddy != g.Cout) return Y4_ERR_SHAPE;
+        return launch_wgrad_f16x2_impl<TN_, TJ_, MS, true>(g, st);
+    }
+    return launch_wgrad_f16x2_impl<TN_, TJ_, MS, false>(g, st);
 }
 
 int f16x2_shape() {
@@ -1333,6 +1488,10 @@ namespace y4 {
 int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts) {
     if (stream1x1_f16x2_ok(g)) return dispatch_stream1x1_f16x2(g, st, nparts);
     if (halo_ok(g)) {
+        if (transposed && g.src_planes) {
+            if (g.Cs_valid != g.Cs) return Y4_ERR_SHAPE;
+            return f16x2_shape() == 16 ? launch_halo_f16x2<true, 16, true>(g, st, nparts) : launch_halo_f16x2<true, 32, true>(g, st, nparts);
+        }
         if (f16x2_shape() == 16) return transposed ? launch_halo_f16x2<true, 16>(g, st, nparts) : launch_halo_f16x2<false, 16>(g, st, nparts);
         return transposed ? launch_halo_f16x2<true, 32>(g, st, nparts) : launch_halo_f16x2<false, 32>(g, st, nparts);
     }

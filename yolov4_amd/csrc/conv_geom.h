@@ -33,6 +33,8 @@ struct ConvGeom {
     // into [2^14, 2^15) before it is split into fp16 pieces, and the epilogue undoes both scales
     const unsigned* src_amax; const unsigned* wt_amax;
     unsigned* dst_amax;           // f16x2 forward, optional: max|finite output| folded in with atomicMax
+    unsigned long long* stamps;   // diagnostic builds only (Y4_STAMPS): cycle sums per loop segment
+    int src_planes;               // f16x2: the gathered tensor is already split: per pixel [Cs hi halfs][Cs lo halfs] (4 Cs bytes)
 };
 
 struct WgradGeom {
@@ -45,6 +47,7 @@ struct WgradGeom {
     int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
     int tn, tj;     // tile edges chosen by the planner (64 or 128)
     const unsigned* x_amax; const unsigned* dy_amax;   // f16x2 mode, as ConvGeom::src_amax
+    int dy_planes;                // f16x2: dy is already split (as ConvGeom::src_planes)
     unsigned long long x_total_bytes, dy_total_bytes;   // whole tensors; blocks re-base their 32-bit windows
 };
 

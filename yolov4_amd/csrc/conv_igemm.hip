@@ -1777,6 +1777,7 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
                 x_amax = hdr + 1;
             }
             g.src_amax = x_amax; g.wt_amax = hdr; g.dst_amax = y_amax;
+            g.stamps = reinterpret_cast<unsigned long long*>(hdr + 16);      // scratch header words 64..127 (diagnostic builds)
             return y4::f16x2_gather(g, false, y4_stream(stream), nparts);
         }
         const int blocks = (int)((nw + 255) / 256 > 4096 ? 4096 : (nw + 255) / 256);
@@ -1838,8 +1839,8 @@ size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
 
 static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx, int lddx,
                            int B, int H, int W, int Cin, int Cout, int k, int stride,
-                           void* workspace, size_t workspace_bytes, const unsigned* dy_amax, const float* residual, int ldr,
-                           void* stream) {
+                           void* workspace, size_t workspace_bytes, const unsigned* dy_amax, int dy_is_planes,
+                           const float* residual, int ldr, void* stream) {
     if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1878,6 +1879,8 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     const long long M = (long long)B * H * W;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cout_pad; g.act = Y4_ACT_LINEAR;
+    if (dy_is_planes && (g_conv_mode != 3 || !dy_amax || Cout_pad != Cout || lddy != Cout)) return Y4_ERR_SHAPE;
+    g.src_planes = dy_is_planes;
     if (g_conv_mode == 3) {
         if (!dy_amax) {
             // pad channels of dy may hold anything: the maximum is taken over the valid channels only
@@ -1886,6 +1889,7 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
             dy_amax = hdr + 1;
         }
         g.src_amax = dy_amax; g.wt_amax = hdr;
+        if (g_scratch && g_scratch_bytes >= SCRATCH_HDR) g.stamps = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(g_scratch) + 16);
         return y4::f16x2_gather(g, true, st, nullptr);
     }
     return dispatch_gather<true>(g, st);
@@ -1893,10 +1897,10 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
 
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
-                        void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
+                        void* workspace, size_t workspace_bytes, const unsigned* dy_amax, int dy_is_planes,
                         const float* residual, int ldr, void* stream) {
     return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, dy_amax,
-                           residual, ldr, stream);
+                           dy_is_planes, residual, ldr, stream);
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
@@ -1909,7 +1913,7 @@ size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, 
 int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
-                        void* stream) {
+                        int dy_is_planes, void* stream) {
     if (!x || !dy || !dw) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1936,6 +1940,7 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
         g.out = dw;
     }
     int rc;
+    if (dy_is_planes && (g_conv_mode != 3 || !dy_amax)) return Y4_ERR_SHAPE;
     if (g_conv_mode == 3) {
         if (!x_amax || !dy_amax) {
             if (!workspace || workspace_bytes < slab_bytes + 64) return Y4_ERR_WORKSPACE;
@@ -1951,7 +1956,7 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
                 dy_amax = hdr + 1;
             }
         }
-        g.x_amax = x_amax; g.dy_amax = dy_amax;
+        g.x_amax = x_amax; g.dy_amax = dy_amax; g.dy_planes = dy_is_planes;
         rc = y4::f16x2_wgrad(g, st);
     } else if (g_conv_mode == 1) {
         if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, 3>(g, st);

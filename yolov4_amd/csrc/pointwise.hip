@@ -220,11 +220,12 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dz, long long lddz, const float* __restrict__ y, long long ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-    long long M, int C, int tpr, int rpb, int nrows, float* __restrict__ part) {
+    long long M, int C, int tpr, int rpb, int nrows, float* __restrict__ part, unsigned* __restrict__ bounds) {
     __shared__ float red[2][PW_THREADS][4];
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     const long long row0 = (long long)blockIdx.x * rpb * nrows;
+    float gmax = 0.f, xmax = 0.f;                          // max |g|, max |xhat| seen by this thread (plane output only)
     for (int cb = 0; cb < C; cb += tpr * 4) {           // uniform trip count: barriers inside
         const int c0 = cb + cv * 4;
         const bool cok = c0 < C;
@@ -255,6 +256,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
                     const float g = ok[u] ? d[u][e] * y4_act_grad(ga[e] * xh + be[e], act) : 0.f;
                     s[e] += g;
                     sx[e] += g * xh;
+                    gmax = fmaxf(gmax, fabsf(g));
+                    xmax = fmaxf(xmax, ok[u] ? fabsf(xh) : 0.f);
                 }
         }
         for (; i < nrows; ++i) {
@@ -268,6 +271,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
                     const float g = d[e] * y4_act_grad(ga[e] * xh + be[e], act);
                     s[e] += g;
                     sx[e] += g * xh;
+                    gmax = fmaxf(gmax, fabsf(g));
+                    xmax = fmaxf(xmax, fabsf(xh));
                 }
             }
         }
@@ -288,19 +293,43 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
         }
         __syncthreads();
     }
+    if (bounds) {                                          // fmaxf drops NaNs; an Inf stays and poisons the bound (-> scale 1)
+        amax_commit(__float_as_uint(gmax), bounds + 0);
+        __syncthreads();
+        amax_commit(__float_as_uint(xmax), bounds + 1);
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ bacc, int nb, int C,
                                                               double* __restrict__ acc, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
+                                                              float* __restrict__ dbeta, const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd, double invM,
+                                                              unsigned* __restrict__ bounds) {
     __shared__ double red[2][8][32];
     double s, ss;
     fold_rows32(bacc, nb, C, blockIdx.x * 32, red, s, ss);
     const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-    if ((threadIdx.x >> 5) != 0 || c >= C) return;
-    acc[c] = s; acc[C + c] = ss;                       // read by the apply pass
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)ss;
+    if ((threadIdx.x >> 5) != 0) return;
+    const bool cok = c < C;
+    if (cok) {
+        acc[c] = s; acc[C + c] = ss;                       // read by the apply pass
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)ss;
+    }
+    if (bounds) {                                          // wave 0 only: maxima over this block's 32 channels
+        float w = cok ? fabsf(gamma[c] * invstd[c]) : 0.f, k1 = cok ? fabsf((float)(s * invM)) : 0.f,
+              k2 = cok ? fabsf((float)(ss * invM)) : 0.f;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            w = fmaxf(w, __shfl_xor(w, off, 64)); k1 = fmaxf(k1, __shfl_xor(k1, off, 64)); k2 = fmaxf(k2, __shfl_xor(k2, off, 64));
+        }
+        if ((threadIdx.x & 31) == 0) {
+            // rounded UP a little: the bound must dominate the fp32 arithmetic of the apply pass
+            atomicMax(bounds + 2, __float_as_uint(w * 1.0001f));
+            atomicMax(bounds + 3, __float_as_uint(k1 * 1.0001f));
+            atomicMax(bounds + 4, __float_as_uint(k2 * 1.0001f));
+        }
+    }
 }
 
 // backward pass 2: dy = gamma*invstd * (g - sum_g/M - xhat * sum_gx/M)
@@ -309,11 +338,27 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const double* __restrict__ acc, float* __restrict__ dy, long long lddy,
-    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds) {
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     const double invM = 1.0 / (double)M;
     unsigned amax = 0u;
+    // plane output (conv mode 3): dy leaves as the two fp16 pieces the conv kernels would otherwise split it into,
+    // per pixel [C hi halfs][C scaled-lo halfs] in the 4C bytes of the fp32 row.  The scale needs max|dy| BEFORE the
+    // sweep: |dy| <= max|gamma invstd| (max|g| + max|k1| + max|xhat| max|k2|), all five maxima left by the reduce /
+    // finalize kernels in bounds[0..4]; the bound goes to bounds[5] for the consumers (same word -> same scale).
+    float ps = 1.f;
+    if (bounds) {
+        const float bnd = __uint_as_float(bounds[2]) *
+                          (__uint_as_float(bounds[0]) + __uint_as_float(bounds[3]) + __uint_as_float(bounds[1]) * __uint_as_float(bounds[4])) * 1.0001f;
+        const unsigned bb = __float_as_uint(bnd);
+        if (blockIdx.x == 0 && tid == 0) bounds[5] = bb;
+        const unsigned e8 = (bb >> 23) & 0xffu;
+        int se = 268 - (int)e8;                            // as f16x2_scale_exp (conv_f16x2.hip)
+        if (e8 == 0u || e8 == 255u) se = 127;
+        se = se < 2 ? 2 : (se > 252 ? 252 : se);
+        ps = __uint_as_float((unsigned)se << 23);
+    }
     for (int c0 = cv * 4; c0 < C; c0 += tpr * 4) {
         f32x4 mu, is, ga, be, k1, k2;
 #pragma unroll
@@ -332,11 +377,27 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
                 const float g = d[e] * y4_act_grad(ga[e] * xh + be[e], act);
                 o[e] = ga[e] * is[e] * (g - k1[e] - xh * k2[e]);
             }
-            st4(dy + m * lddy + c0, o);
-            amax_track(amax, o);
+            if (bounds) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                h2 h01, h23, l01, l23;
+                const float t0 = o[0] * ps, t1 = o[1] * ps, t2 = o[2] * ps, t3 = o[3] * ps;
+                h01[0] = (_Float16)t0; h01[1] = (_Float16)t1; h23[0] = (_Float16)t2; h23[1] = (_Float16)t3;
+                l01[0] = (_Float16)((t0 - (float)h01[0]) * 2048.f); l01[1] = (_Float16)((t1 - (float)h01[1]) * 2048.f);
+                l23[0] = (_Float16)((t2 - (float)h23[0]) * 2048.f); l23[1] = (_Float16)((t3 - (float)h23[1]) * 2048.f);
+                unsigned short* row = reinterpret_cast<unsigned short*>(dy + m * lddy);
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                u2 hv, lv;
+                hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
+                lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
+                *reinterpret_cast<u2*>(row + c0) = hv;
+                *reinterpret_cast<u2*>(row + C + c0) = lv;
+            } else {
+                st4(dy + m * lddy + c0, o);
+                amax_track(amax, o);
+            }
         }
     }
-    if (out_amax) amax_commit(amax, out_amax);
+    if (out_amax && !bounds) amax_commit(amax, out_amax);
 }
 
 __global__ __launch_bounds__(PW_THREADS) void colsum_kernel(const float* __restrict__ x, long long ldx, long long M,
@@ -705,7 +766,8 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
 int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,
-                      long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax, void* stream) {
+                      long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
+                      unsigned* f16_planes, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
@@ -717,17 +779,19 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
     const int nrows = stat_rows(M, rm.rpb);
     const long long rblocks = bn_blocks(M, C);
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((unsigned)rblocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz,
-                       y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, nrows, part);
+                       y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, nrows, part, f16_planes);
     Y4_CHECK_LAUNCH();
     int nb = 0;
     { const int rc = fold_partials(part, rblocks, C, bacc, &nb, st); if (rc != Y4_OK) return rc; }
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta);
+    if (f16_planes && (lddy != C || (C & 31))) return Y4_ERR_SHAPE;       // planes: dense rows, whole 32-channel K-tiles
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta, gamma,
+                       invstd, 1.0 / (double)M, f16_planes);
     Y4_CHECK_LAUNCH();
     long long blocks = (M + rm.rpb - 1) / rm.rpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
                        (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,
-                       out_amax);
+                       out_amax, f16_planes);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -121,26 +121,30 @@ def _ws(nbytes, device):
 # a device word ("cell") that travels with the tensor as the Python attribute `y4_amax`.  Cells of tensors that share
 # a concat buffer are one shared cell (atomicMax).  A tensor without a cell is always legal: the consumer then spends
 # one extra pass over it (ops.amax_raw / inside the library).
-_AMAX = {'pool': {}, 'N': 4096}
+_AMAX = {'pool': {}, 'N': 8192}
 
 
 def f16x2_mode():
     return lib().y4_get_conv_mode() == 3
 
 
-def new_amax(device):
-    """A zeroed device word out of a ring of 4096; each half is re-zeroed (one tiny fill) when the ring enters it, i.e.
-    >= 2048 allocations (several training steps) after its cells were handed out."""
+def new_amax(device, n=1):
+    """n (1 or 8) zeroed device words out of a ring of 8192; each half is re-zeroed (one tiny fill) when the ring enters
+    it, i.e. >= 4096 words (several training steps) after its cells were handed out."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _AMAX['pool'].get(key)
     if st is None:
         st = {'buf': torch.zeros(_AMAX['N'], dtype=torch.int32, device=device), 'i': 0}
         _AMAX['pool'][key] = st
-    i, half = st['i'], _AMAX['N'] // 2
-    if i % half == 0:
-        st['buf'][i:i + half].zero_()
-    st['i'] = (i + 1) % _AMAX['N']
-    return st['buf'][i:i + 1]
+    half = _AMAX['N'] // 2
+    i = (st['i'] + n - 1) // n * n                    # n-word blocks are n-aligned, so they never straddle a half
+    if i >= _AMAX['N']:
+        i = 0
+    if i // half != (st['i'] - 1) // half or st['i'] == 0:
+        h0 = i // half * half
+        st['buf'][h0:h0 + half].zero_()
+    st['i'] = i + n
+    return st['buf'][i:i + n]
 
 
 def amax_of(t):
@@ -236,7 +240,7 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     return y, mean, invstd
 
 
-def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None):
+def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=False):
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
@@ -249,7 +253,8 @@ def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None):
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
     check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
-                                _ptr(ws), nbytes, _ptr(dy_amax), _ptr(residual), ldr, _stream()), 'conv2d_dgrad')
+                                _ptr(ws), nbytes, _ptr(dy_amax), 1 if dy_planes else 0, _ptr(residual), ldr, _stream()),
+          'conv2d_dgrad')
     return dx
 
 
@@ -262,10 +267,11 @@ def _is_krsc_dense(t):
     return t.dtype == torch.float32 and all(t.shape[i] == 1 or st[i] == exp[i] for i in range(4))
 
 
-WGRAD_STATS = {'in_place': 0, 'temporary': 0}      # filter gradients written into a caller slot vs a temporary
+WGRAD_STATS = {'in_place': 0, 'temporary': 0}
+DY_PLANES = {'dgrad': os.environ.get('Y4_DY_PLANES', '0') == '1'}      # experimental: see ConvBNActFn.backward      # filter gradients written into a caller slot vs a temporary
 
 
-def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None):
+def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None, dy_planes=False):
     """out: optional fp32 tensor of shape w_shape whose memory is dense KRSC (e.g. a gradient slot of a flat
     DDP bucket): the kernel then writes the filter gradient in place."""
     L = lib()
@@ -291,7 +297,7 @@ def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None):
     nbytes = L.y4_conv2d_wgrad_workspace(B, H, W, Cin, Cout, k, s)
     ws = _ws(nbytes, dy.device)
     check(L.y4_conv2d_wgrad_f32(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, H, W, Cin, Cout, k, s,
-                                _ptr(ws), nbytes, _ptr(x_amax), _ptr(dy_amax), _stream()), 'conv2d_wgrad')
+                                _ptr(ws), nbytes, _ptr(x_amax), _ptr(dy_amax), 1 if dy_planes else 0, _stream()), 'conv2d_wgrad')
     return dw
 
 
@@ -331,7 +337,7 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
     return z
 
 
-def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None):
+def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None):
     """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
     L = lib()
     B, C, H, W = y.shape
@@ -347,7 +353,7 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
-                              _ptr(ws), nbytes, _ptr(out_amax), _stream()), 'bn_act_bwd')
+                              _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), _stream()), 'bn_act_bwd')
     return dy, dgamma, dbeta
 
 
@@ -423,14 +429,14 @@ def join_side_stream(device=None):
     _ASYNC['join_queued'] = False
 
 
-def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None):
+def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None, dy_planes=False):
     """wgrad on the side stream, accumulated straight into param.grad (autograd gets None for this input)."""
     main = torch.cuda.current_stream(x.device)
     side = side_stream(x.device)
     ev = main.record_event()
     with torch.cuda.stream(side):
         side.wait_event(ev)
-        dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s, x_amax=x_amax, dy_amax=dy_amax)
+        dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s, x_amax=x_amax, dy_amax=dy_amax, dy_planes=dy_planes)
         if param.grad is None:
             dw.record_stream(main)          # allocated in the side stream's pool, consumed (and freed) on the main one
             param.grad = dw
@@ -514,15 +520,20 @@ class ConvBNActFn(torch.autograd.Function):
         k, s, act = cfg['k'], cfg['s'], cfg['act']
         f16 = f16x2_mode() and ctx.x_shape[1] != 3
         dy_amax = None
+        dy_planes = False
         if ctx.mode == 'bn_train':
             x, weight, y, mean, invstd, gamma, beta = ctx.saved_tensors
             gp, bp = cfg.get('gamma_param'), cfg.get('beta_param')
             sink = (gp is not None and bp is not None and getattr(gp, '_y4_grad_fresh', False)
                     and getattr(bp, '_y4_grad_fresh', False) and gp.grad is not None and bp.grad is not None
                     and ctx.needs_input_grad[3] and ctx.needs_input_grad[4])
-            dy_amax = new_amax(dz.device) if f16 else None
+            # conv mode 3: dy leaves the BatchNorm backward sweep already split into its two fp16 planes (DY_PLANES)
+            planes = new_amax(dz.device, 8) if (f16 and DY_PLANES['dgrad'] and y.shape[1] % 32 == 0) else None
+            dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
-                                               gp.grad if sink else None, bp.grad if sink else None, out_amax=dy_amax)
+                                               gp.grad if sink else None, bp.grad if sink else None,
+                                               out_amax=None if planes is not None else dy_amax, planes=planes)
+            dy_planes = planes is not None
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
                 gp._y4_grad_fresh = bp._y4_grad_fresh = False
@@ -548,24 +559,25 @@ class ConvBNActFn(torch.autograd.Function):
                 raise Y4Error('gradient wrt the network input (stem, Cin=3) is not implemented')
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
-            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad)
+            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad, dy_planes=dy_planes)
         elif skip_grad is not None:
             raise Y4Error('a parked skip gradient has no consumer (input of the 1x1 conv does not require grad)')
         dw = None
         if ctx.needs_input_grad[1]:
             param = cfg.get('weight_param')
             if _ASYNC['on'] and param is not None and param.requires_grad:
-                _wgrad_to_param(x, dy, param, k, s, ctx.x_amax, dy_amax)          # lands in param.grad on the side stream
+                _wgrad_to_param(x, dy, param, k, s, ctx.x_amax, dy_amax, dy_planes)   # lands in param.grad on the side stream
             elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
                 # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place
                 # (no temporary, no accumulate pass); the bucket is told directly, autograd gets None
                 param._y4_grad_fresh = False
-                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad, x_amax=ctx.x_amax, dy_amax=dy_amax)
+                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad, x_amax=ctx.x_amax, dy_amax=dy_amax,
+                                     dy_planes=dy_planes)
                 if got is not param.grad:
                     param.grad.add_(got)
                 param._y4_grad_ready()
             else:
-                dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, x_amax=ctx.x_amax, dy_amax=dy_amax)
+                dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, x_amax=ctx.x_amax, dy_amax=dy_amax, dy_planes=dy_planes)
         dres = dz if ctx.has_res else None
         put = cfg.get('dres_put')
         if dres is not None and put is not None:
