@@ -37,3 +37,14 @@ for name in sorted(acc, key=lambda k: -dur[k])[:16]:
         if k in c:
             line += f' {k[9:].lower()}/launch {c[k] / n[name]:.3g}'
     print(line)
+    extra = ''
+    if c.get('TCC_HIT_sum') is not None and (c.get('TCC_HIT_sum', 0) + c.get('TCC_MISS_sum', 0)) > 0:
+        extra += f" L2-hit {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.3f} L2-req/launch {(c['TCC_HIT_sum'] + c['TCC_MISS_sum']) / n[name]:.3g}"
+    for k in ('TCC_EA0_RDREQ_sum', 'TCC_EA0_RDREQ_32B_sum', 'TCC_REQ_sum', 'TCC_READ_sum', 'TCP_TCC_READ_REQ_sum', 'TCP_TOTAL_CACHE_ACCESSES_sum',
+              'TCP_TCC_READ_REQ_LATENCY_sum', 'TCP_PENDING_STALL_CYCLES_sum', 'TCP_GATE_EN1_sum', 'TCP_GATE_EN2_sum', 'TCP_TA_TCP_STATE_READ_sum',
+              'TA_BUSY_avr', 'TA_ADDR_STALLED_BY_TC_CYCLES_sum', 'TA_DATA_STALLED_BY_TC_CYCLES_sum', 'TCC_BUSY_avr', 'TCC_TAG_STALL_sum',
+              'TCP_READ_TAGCONFLICT_STALL_CYCLES_sum', 'TCP_TCR_TCP_STALL_CYCLES_sum', 'FETCH_SIZE', 'WRITE_SIZE', 'MemUnitStalled', 'L2CacheHit'):
+        if k in c:
+            extra += f' {k} {c[k] / n[name]:.4g}'
+    if extra:
+        print('      ' + extra)

@@ -6,21 +6,6 @@ from yolov4_amd import ops
 yolov4_amd.set_conv_mode('f16x2')
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
-for (ci, co, k, H) in [(256, 512, 3, 38), (128, 128, 3, 76), (512, 256, 1, 38), (512, 1024, 3, 19)]:
-    x = torch.randn((64, ci, H, H), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
-    w = (torch.randn((co, ci, k, k), generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
-    ops.conv_fwd_raw(x, w, k, 1); torch.cuda.synchronize()
-    scratch = ops._SCRATCH[('cuda', 0)]
-    st = scratch[64:64 + 64].view(torch.int64)
-    st.zero_()
-    for _ in range(3): ops.conv_fwd_raw(x, w, k, 1)
-    torch.cuda.synchronize()
-    v = st[:5].cpu().tolist()
-    tot = sum(v[:4])
-    print(f'{ci}->{co} k{k} @{H}: per wave-iteration cycles: store {v[0]/v[4]:.0f} load {v[1]/v[4]:.0f} compute {v[2]/v[4]:.0f} barrier {v[3]/v[4]:.0f} '
-          f'| shares store {v[0]/tot:.2f} load {v[1]/tot:.2f} compute {v[2]/tot:.2f} barrier {v[3]/tot:.2f}', flush=True)
-
-
 def stamps_of(fn, label):
     fn(); torch.cuda.synchronize()
     st = ops._SCRATCH[('cuda', 0)][64:64 + 64].view(torch.int64)
@@ -34,6 +19,14 @@ def stamps_of(fn, label):
           f'barrier {v[3]/v[4]:.0f} | shares {v[0]/tot:.2f} {v[1]/tot:.2f} {v[2]/tot:.2f} {v[3]/tot:.2f}', flush=True)
 
 
+print('forward')
+for (ci, co, k, H) in [(256, 512, 3, 38), (128, 128, 3, 76), (512, 256, 1, 38), (512, 1024, 3, 19)]:
+    x = torch.randn((64, ci, H, H), generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((co, ci, k, k), generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    ops.conv_fwd_raw(x, w, k, 1); torch.cuda.synchronize()
+    stamps_of(lambda: ops.conv_fwd_raw(x, w, k, 1), f'{ci}->{co} k{k} @{H}')
+if os.environ.get('Y4_PROBE_FWD_ONLY'):
+    sys.exit(0)
 print('dgrad, fp32 dy vs pre-split dy planes')
 for (ci, co, k, H) in [(256, 512, 3, 38), (128, 128, 3, 76), (512, 256, 1, 38), (512, 1024, 3, 19)]:
     x = torch.randn((64, ci, H, H), generator=g).to(dev).contiguous(memory_format=torch.channels_last)

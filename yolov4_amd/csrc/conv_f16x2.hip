@@ -18,8 +18,12 @@
 // K-tile: [barrier] split + write tile t+1 into the other stage, issue the global loads of tile t+2, MFMAs of tile t.
 #include <stdlib.h>
 #include "common.h"
+#include <cstdlib>
 #include "conv_geom.h"
 
+#ifndef Y4_KNOCK
+#define Y4_KNOCK 0      // diagnostic builds only: 1 = no global loads in the K loop, 2 = no operand split, 3 = no MFMA
+#endif
 #ifndef Y4_STAMPS
 #define Y4_STAMPS 0
 #endif
@@ -112,11 +116,13 @@ constexpr int ROWB = 64;                                   // bytes per LDS row 
 // TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
 // APL: the gathered tensor arrives pre-split (ConvGeom::src_planes: dy planes written by the BatchNorm backward sweep);
 //      its tile is then staged like the filter tile -- 16-B loads of each plane, ds_write_b128, no VALU.
+__device__ unsigned g_cu_arrivals[8 * 256];     // blocks seen per CU (stagger experiment)
+
 template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int MS, bool APL = false>
 __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     constexpr int BK = 32;
     constexpr int PA = APL ? (BM * 4 + 255) / 256 : BM / 32;   // A items per thread: 16-B plane chunks, or fp32 row chunks
-    constexpr int NB = (BN * 4 + 255) / 256;               // 16-B chunks of the B tile per thread and plane
+    constexpr int NB = (BN * 8 + 255) / 256;               // 16-B chunks of the B tile per thread (both planes)
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MS, TN = WTN / MS;
     constexpr int ACCN = MS == 32 ? 16 : 4;
@@ -199,19 +205,20 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     }
     unsigned b_off[NB];
     int b_lds[NB];
-    const unsigned plane_bytes = (unsigned)g.N * (unsigned)g.K * 2u;
+    // filter planes are interleaved per 32-deep K-tile: row n = [tile 0: 64 B hi | 64 B lo][tile 1: ...] -- the 8 lanes
+    // of a row read one whole 128-B line (half lines per instruction cost the texture addresser twice the cycles)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int slot = tid + 256 * i;
-        const int row = slot >> 2, ch = slot & 3;
+        const int row = slot >> 3, ch = slot & 3, bpl = (slot >> 2) & 1;
         const bool ok = row < BN && (n0 + row) < g.N;
-        b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 2u + ch * 16u : OOB;
-        b_lds[i] = row < BN ? row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
+        b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 4u + (unsigned)(slot & 7) * 16u : OOB;
+        b_lds[i] = row < BN ? bpl * BN * ROWB + row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
     }
 
     f32x4 ra[APL ? 1 : PA];
     u32x4 rap[APL ? PA : 1][2];                            // APL: hi / lo plane chunks
-    u32x4 rb[NB][2];
+    u32x4 rb[NB];
     const int CC = g.Cs / BK;
     const unsigned a_lo = (unsigned)g.Cs * 2u;             // APL: byte offset of the lo plane inside a pixel row
     int r = r0, q = q0, cc = 0;
@@ -242,15 +249,16 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                 rap[p][1] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u + a_lo), 0);
             }
         } else {
+#if Y4_KNOCK != 4
 #pragma unroll
             for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
+#endif
         }
-        const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 2u);
+        const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 4u);
+#if Y4_KNOCK != 5
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)(koff + pl * plane_bytes), 0);
+        for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)koff, 0);
+#endif
         if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } tap_setup(); }
     };
     int st_cc = 0;
@@ -274,15 +282,19 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
             }
             u32x2 hi, lo;
+#if Y4_KNOCK == 2
+            hi[0] = __builtin_bit_cast(unsigned, v[0]); hi[1] = __builtin_bit_cast(unsigned, v[1]);
+            lo[0] = __builtin_bit_cast(unsigned, v[2]); lo[1] = __builtin_bit_cast(unsigned, v[3]);
+#else
             split2x4(v, sa, hi, lo);
+#endif
             *reinterpret_cast<u32x2*>(as + a_lds[p]) = hi;
             *reinterpret_cast<u32x2*>(as + BM * ROWB + a_lds[p]) = lo;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             if (b_lds[i] >= 0) {
-                *reinterpret_cast<u32x4*>(bs + b_lds[i]) = rb[i][0];
-                *reinterpret_cast<u32x4*>(bs + BN * ROWB + b_lds[i]) = rb[i][1];
+                *reinterpret_cast<u32x4*>(bs + b_lds[i]) = rb[i];
             }
         if (++st_cc == CC) st_cc = 0;
     };
@@ -343,15 +355,32 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     fa[pl] = *reinterpret_cast<const f16x8*>(base + pl * BM * ROWB + a_row + i * 16 * ROWB + co);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
+#if Y4_KNOCK == 3
+                    asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fb[j][0]), "v"(fb[j][1]));
+#else
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[j][0], acc1[i][j], 0, 0, 0);
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][1], acc1[i][j], 0, 0, 0);
                     acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][0], acc0[i][j], 0, 0, 0);
+#endif
                 }
             }
         }
     };
 
     const int KT = nr * nq * CC;
+    if (g.stagger > 0) {
+        // Two blocks share a CU (one wave of each per SIMD).  Launched together they run their phases (split, load
+        // issue, MFMA) in lockstep, each unit contended twice over and idle otherwise; the block in the odd wave
+        // slot starts half an iteration late so that one block's MFMAs cover the other's loads and splits.
+        const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | 4);        // HW_ID[15:0]: ... CU_ID[11:8] SH_ID[12] SE_ID[15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // XCC_ID[3:0]
+        if (tid == 0) row_m[0] = (int)atomicAdd(&g_cu_arrivals[(xcc & 7) * 256 + ((hw >> 8) & 255)], 1u);
+        __syncthreads();
+        const int arrival = row_m[0];
+        __syncthreads();
+        if (arrival & 1)
+            for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     load_tile();
     store_tile(0);
     if (KT > 1) load_tile();
@@ -365,7 +394,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         Y4_T(a0);
         if (kt + 1 < KT) store_tile((kt + 1) & 1);
         Y4_T(a1);
+#if Y4_KNOCK != 1
         if (kt + 2 < KT) load_tile();
+#endif
+#if Y4_KNOCK == 6
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // exposes the raw load latency in the 'load' segment
+#endif
         Y4_T(a2);
         compute(kt & 1);
         asm volatile("s_nop 0" ::: "memory");
@@ -726,7 +760,7 @@ constexpr int HALO_ROWS = 304;                             // patch capacity (ro
 template <int BN, bool TRANSPOSED, int MS, bool APL = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, const int tiles_per_img) {
     constexpr int BM = 128, WM = 2, WN = 2;
-    constexpr int NB = (BN * 4 + 255) / 256;
+    constexpr int NB = (BN * 8 + 255) / 256;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MS, TN = WTN / MS;
     constexpr int ACCN = MS == 32 ? 16 : 4;
@@ -779,27 +813,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
     // ---- filter chunks of this thread
     unsigned b_off[NB];
     int b_lds[NB];
-    const unsigned plane_bytes = (unsigned)g.N * (unsigned)g.K * 2u;
+    // filter planes are interleaved per 32-deep K-tile: row n = [tile 0: 64 B hi | 64 B lo][tile 1: ...] -- the 8 lanes
+    // of a row read one whole 128-B line (half lines per instruction cost the texture addresser twice the cycles)
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int slot = tid + 256 * i;
-        const int row = slot >> 2, ch = slot & 3;
+        const int row = slot >> 3, ch = slot & 3, bpl = (slot >> 2) & 1;
         const bool ok = row < BN && (n0 + row) < g.N;
-        b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 2u + ch * 16u : OOB;
-        b_lds[i] = row < BN ? row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
+        b_off[i] = ok ? (unsigned)(n0 + row) * (unsigned)g.K * 4u + (unsigned)(slot & 7) * 16u : OOB;
+        b_lds[i] = row < BN ? bpl * BN * ROWB + row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
     }
     const int CC = g.Cs / 32;
     const int S = 9 * CC;                                  // steps: s = cc * 9 + tap
-    u32x4 rb[NB][2];
+    u32x4 rb[NB];
     int ld_s = 0;
     auto load_b = [&]() {
         const int cc = ld_s / 9, tap = ld_s - cc * 9;
-        const unsigned koff = (unsigned)(tap * CC + cc) * 64u;
+        const unsigned koff = (unsigned)(tap * CC + cc) * 128u;
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
-                rb[i][pl] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)(koff + pl * plane_bytes), 0);
+        for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)koff, 0);
         ++ld_s;
     };
     auto store_b = [&](int buf) {
@@ -807,8 +839,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             if (b_lds[i] >= 0) {
-                *reinterpret_cast<u32x4*>(bs + b_lds[i]) = rb[i][0];
-                *reinterpret_cast<u32x4*>(bs + BN * ROWB + b_lds[i]) = rb[i][1];
+                *reinterpret_cast<u32x4*>(bs + b_lds[i]) = rb[i];
             }
     };
     auto stage_patch = [&](int cc) {
@@ -1066,7 +1097,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
             const int rem = i - pl * (N32 * CPR);
             const int row = rem / CPR, ch = rem - row * CPR;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < g.N) v = *reinterpret_cast<const u32x4*>(wp + ((size_t)pl * g.N + row) * (K * 2) + ch * 16);
+            if (row < g.N) v = *reinterpret_cast<const u32x4*>(wp + (size_t)row * (K * 4) + (ch >> 2) * 128 + pl * 64 + (ch & 3) * 16);
             *reinterpret_cast<u32x4*>(smem_b + (pl * N32 + row) * PITCH + ch * 16) = v;
         }
     }
@@ -1285,8 +1316,9 @@ __global__ __launch_bounds__(256) void f16x2_split_filter_kernel(const float* __
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         unsigned short hi, lo;
         split2(w[i], s, hi, lo);
-        planes[i] = hi;
-        planes[n + i] = lo;
+        const long long o = (i >> 5) * 64 + (i & 31);          // per 32-deep K-tile: [32 hi][32 lo] (rows are whole K-tiles)
+        planes[o] = hi;
+        planes[o + 32] = lo;
     }
 }
 
@@ -1305,8 +1337,9 @@ __global__ __launch_bounds__(256) void f16x2_transpose_split_filter_kernel(const
         const float v = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
         unsigned short hi, lo;
         split2(v, s, hi, lo);
-        planes[i] = hi;
-        planes[total + i] = lo;
+        const long long o = (i >> 5) * 64 + (i & 31);
+        planes[o] = hi;
+        planes[o + 32] = lo;
     }
 }
 
@@ -1391,7 +1424,15 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
         if (!g.wt_planes) return Y4_ERR_WORKSPACE;
         g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
     }
-    const size_t smem = 2ull * 2 * (BM + BN) * ROWB + BM * sizeof(int);
+    size_t smem = 2ull * 2 * (BM + BN) * ROWB + BM * sizeof(int);
+#if Y4_STAMPS
+    if (const char* e = getenv("Y4_EXTRA_LDS")) smem += (size_t)atoi(e);      // diagnostic: lower the occupancy
+#endif
+    {
+        static int stg = -1;
+        if (stg < 0) { const char* e = getenv("Y4_STAGGER"); stg = e ? atoi(e) : 0; }
+        g.stagger = stg;
+    }
     auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS, APL>;
     static bool attr_done = false;
     if (!attr_done) {

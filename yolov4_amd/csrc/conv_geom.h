@@ -33,6 +33,7 @@ struct ConvGeom {
     // into [2^14, 2^15) before it is split into fp16 pieces, and the epilogue undoes both scales
     const unsigned* src_amax; const unsigned* wt_amax;
     unsigned* dst_amax;           // f16x2 forward, optional: max|finite output| folded in with atomicMax
+    int stagger;                  // > 0: blocks in an odd wave slot start their K loop 64*stagger cycles late (see conv_f16x2.hip)
     unsigned long long* stamps;   // diagnostic builds only (Y4_STAMPS): cycle sums per loop segment
     int src_planes;               // f16x2: the gathered tensor is already split: per pixel [Cs hi halfs][Cs lo halfs] (4 Cs bytes)
 };
