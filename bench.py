@@ -49,6 +49,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--ddp-timeline', action='store_true',
+                    help='record when each gradient bucket becomes ready inside the backward pass (adds ddp_timeline to the line)')
     ap.add_argument('--conv-mode', default='f16x2', choices=['f16x2', 'bf16x3', 'f32', 'bf16'],
                     help='conv arithmetic: 2-piece fp16 split (fp32-grade, 3 MFMAs per product, default), exact 3-way bf16 '
                          'split (6 MFMAs), the fp32 MFMA fma chain, or plain bf16 operands (mixed precision)')
@@ -80,7 +82,8 @@ class ConvTimer:
                 out = fn(*a, **kw)
                 e1.record()
                 fl, key = flops_of(*a, **kw)
-                timer.rec.append((kind, fl, e0, e1, key, timer.sym))
+                # the library names the kernel it launched (f16x2 mode); other modes: the dispatch rules restated below
+                timer.rec.append((kind, fl, e0, e1, key, ops.last_conv_kernel() or timer.sym))
                 return out
             return inner
 
@@ -400,6 +403,8 @@ def main():
     model.load_state_dict(sd)
     model = model.to(dev).train()
     ddp = BucketedDDP(model, bucket_mb=25.0)
+    if args.ddp_timeline:
+        ddp.record_timeline()
     crit = YOLOLoss(cfg, ignore_thresh=0.7, device=dev)
 
     B, S = args.batch, args.size
@@ -453,6 +458,13 @@ def main():
                        'peak_hbm_gib': round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
                        'loss': lossv, 'conv_tflops_whole_step': value / world * flop_img / 1e12},
         }
+        if args.ddp_timeline:
+            tl = ddp.timeline()           # of the last timed step
+            out['ddp_timeline'] = {
+                'note': 'per gradient bucket of the LAST step: MiB, ms after the first gradient hook of the backward pass at which '
+                        'its last gradient has landed (= earliest start of its all-reduce), ms of backward work still to run after that',
+                'buckets': [{'bucket': i, 'mib': round(nb / 2**20, 2), 'ready_ms': round(a, 2), 'backward_left_ms': round(b, 2)}
+                            for i, nb, a, b in tl]}
         if timer.rec:
             summ = timer.summary()
             syms = timer.by_symbol()

@@ -98,6 +98,11 @@ int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy
 int y4_amax_f32(const float* x, int ldx, long long M, int C, unsigned* amax_bits, void* stream);
 int y4_amax_merge_u32(unsigned* dst, const unsigned* src, void* stream);
 
+/* Measurement aid (bench.py): copies the symbol of the conv kernel the calling host thread launched last, spelled as
+ * rocprofv3 --stats prints it, into buf (NUL-terminated, at most cap bytes) and clears it; empty when the last launch
+ * was not an f16x2-mode kernel.  No reference counterpart. */
+int y4_last_conv_kernel(char* buf, int cap);
+
 /* Training-mode variant: raw conv output + BatchNorm batch statistics fused into the epilogue.
  * partials receives one row [2][Cout] (column sums, sums of squares) per M-tile; *nparts_host
  * (HOST int64) is set to the number of rows written; feed both to y4_bn_finalize_partials_f32.

@@ -38,6 +38,7 @@ def test_convbnact_ctx_does_not_hold_its_output(monkeypatch):
         return z
 
     monkeypatch.setattr(ops, '_require_gpu', lambda t, what: None)
+    monkeypatch.setattr(ops, 'f16x2_mode', lambda: False)      # no operand maxima (device kernels) in this host-logic test
     monkeypatch.setattr(ops, 'conv_fwd_bnstats_raw', fake_bnstats)
     monkeypatch.setattr(ops, 'bn_act_fwd_raw', fake_bn_act)
     m = ConvBNAct(8, 8, 1, 1).train()

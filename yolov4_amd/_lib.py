@@ -33,6 +33,7 @@ PROTOTYPES = {
     'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P, P]),
     'y4_amax_f32': (I, [P, I, L, I, P, P]),
     'y4_amax_merge_u32': (I, [P, P, P]),
+    'y4_last_conv_kernel': (I, [ctypes.c_char_p, I]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
     'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P]),
     'y4_conv2d_stem_fwd_f32': (I, [P, L, L, L, L, P, P, I, I, I, I, I, P, P, I, P, P]),

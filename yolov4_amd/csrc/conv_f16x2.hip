@@ -1070,6 +1070,7 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
+    y4::note_kernel("conv3x3_halo_f16x2<%d, %s, %d, %s>", BN, TR ? "true" : "false", MS, APL ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(256), smem, st, g, tiles_per_img);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1278,6 +1279,7 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     const int resident = NW == 8 ? 256 : 512;             // blocks per CU: 1 (8 waves) or 2
     const int grid = g.mtiles < resident ? g.mtiles : resident;
     if (nparts) *nparts = grid;
+    y4::note_kernel("conv1x1_stream_f16x2<%d, %d, %d, %s>", KS, NT, NW, APL ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1450,6 +1452,7 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
         g.cls_slot0[4] = sl;
         grid = sl * 8;
     }
+    y4::note_kernel("conv_gather_f16x2<%d, %d, %d, %d, %s, %d, %s>", BM, BN, WM, WN, TR ? "true" : "false", MS, APL ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1498,6 +1501,7 @@ int launch_wgrad_f16x2_impl(const WgradGeom& g, hipStream_t st) {
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
+    y4::note_kernel("conv_wgrad_f16x2<%d, %d, %d, %s>", TN_, TJ_, MS, APL ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;

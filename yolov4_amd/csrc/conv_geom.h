@@ -61,4 +61,8 @@ int f16x2_transpose_split_filter(const float* w, unsigned short* planes, int Cou
 int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st);   // zeroes the word first
 int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st);
 
+
+// Name of the conv kernel launched last on this host thread, spelled as rocprofv3 prints the symbol (bench.py names the
+// dominant kernel with it instead of restating the dispatch rules).
+void note_kernel(const char* fmt, ...);
 }  // namespace y4

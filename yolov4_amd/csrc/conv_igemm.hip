@@ -12,6 +12,8 @@
 // groups), double buffered, register-staged global loads issued one K-tile ahead.
 #include <stdlib.h>
 #include "common.h"
+#include <cstdarg>
+#include <cstdio>
 #include "conv_geom.h"
 
 namespace {
@@ -644,6 +646,17 @@ __global__ void transpose_split_filter_kernel(const float* __restrict__ w, unsig
     }
 }
 
+thread_local char g_last_kernel[160] = "";          // see y4::note_kernel
+}
+namespace y4 {
+void note_kernel(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
+}
+}
+namespace {
 // process-wide scratch arena for library temporaries (pre-split filters); set by y4_set_workspace
 void* g_scratch = nullptr;
 size_t g_scratch_bytes = 0;
@@ -1901,6 +1914,13 @@ int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, in
                         const float* residual, int ldr, void* stream) {
     return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, dy_amax,
                            dy_is_planes, residual, ldr, stream);
+}
+
+int y4_last_conv_kernel(char* buf, int cap) {
+    if (!buf || cap <= 0) return Y4_ERR_NULL;
+    snprintf(buf, (size_t)cap, "%s", g_last_kernel);
+    g_last_kernel[0] = 0;
+    return Y4_OK;
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {

@@ -216,6 +216,80 @@ __global__ void yolo_assign_kernel(const float* __restrict__ labels, int K, int 
     w.npos[b] = np;
 }
 
+// The same assignment with one wave per image (K <= 64 labels, one lane each): the per-label work (anchor argmax, cell,
+// regression targets) is independent; the sequential rules of the loop above become lane-order rules -- a cell's record
+// belongs to the first label that hits it (records numbered in that order), its values come from the LAST such label,
+// its class bits are the OR over all of them.
+__global__ __launch_bounds__(64) void yolo_assign_wave_kernel(const float* __restrict__ labels, int K, int B, int F, int A,
+                                                              int C, int cw, float stride, Anchors all_anc, int n_all,
+                                                              int m0, int m1, int m2, Anchors masked, LossPtrs w) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* lab = labels + (long long)b * K * 5;
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f, l4 = 0.f;
+    if (t < K) { l0 = lab[t * 5]; l1 = lab[t * 5 + 1]; l2 = lab[t * 5 + 2]; l3 = lab[t * 5 + 3]; l4 = lab[t * 5 + 4]; }
+    const float s = (((l0 + l1) + l2) + l3) + l4;
+    const int n = __popcll(__ballot(t < K && s > 0.f));
+    if (t == 0) w.nlabel[b] = n;
+    const bool act = t < n;
+    const float tx = l0 / stride, ty = l1 / stride, tw = l2 / stride, th = l3 / stride;
+    if (act) {
+        float* tr = w.truth + ((long long)b * K + t) * 4;
+        tr[0] = tx; tr[1] = ty; tr[2] = tw; tr[3] = th;
+    }
+    int best = 0;
+    float best_iou = -INFINITY;
+    bool first = true;
+    for (int k = 0; k < n_all; ++k) {
+        const float aw = all_anc.w[k], ah = all_anc.h[k];
+        const float brx = fminf(tw, aw), bry = fminf(th, ah);
+        const float en = (0.f < brx && 0.f < bry) ? 1.f : 0.f;
+        const float ai = (brx * bry) * en;
+        const float iou = ai / ((tw * th + aw * ah) - ai);
+        if (first || iou > best_iou || (iou != iou && !(best_iou != best_iou))) { best = k; best_iou = iou; first = false; }
+    }
+    const int a = best % 3;
+    const int i = (int)(short)(int)tx, j = (int)(short)(int)ty;
+    const bool pos = act && (best == m0 || best == m1 || best == m2) && i >= 0 && i < F && j >= 0 && j < F && a < A;
+    const int cell = pos ? (a * F + j) * F + i : -1 - t;                      // non-positive lanes never match anyone
+    const int cls = (int)(short)(int)l4;
+    const unsigned long long pm = __ballot(pos);
+    int owner = t;
+    bool later_same = false;
+    for (int u = 0; u < 64; ++u) {
+        const int cu = __shfl(cell, u, 64);
+        if (((pm >> u) & 1ull) && cu == cell) {
+            if (u < owner) owner = u;
+            if (u > t) later_same = true;
+        }
+    }
+    const bool is_owner = pos && owner == t;
+    const unsigned long long om = __ballot(is_owner);
+    const int my_rank = __popcll(om & ((1ull << t) - 1ull));
+    const int rec = __shfl(my_rank, owner, 64);
+    for (int q = 0; q < cw; ++q) {
+        unsigned word = 0u;
+        for (int u = 0; u < 64; ++u) {
+            const int cu = __shfl(cell, u, 64), ku = __shfl(cls, u, 64);
+            if (((pm >> u) & 1ull) && cu == cell && ku >= 0 && ku < C && (ku >> 5) == q) word |= 1u << (ku & 31);
+        }
+        if (is_owner) w.pos_cls[((long long)b * K + rec) * cw + q] = word;
+    }
+    if (is_owner) {
+        w.pos_cell[(long long)b * K + rec] = cell;
+        w.pos_index[(long long)b * A * F * F + cell] = rec;
+    }
+    if (pos && !later_same) {
+        const float Ff = (float)F;
+        float* pv = w.pos_val + ((long long)b * K + rec) * 5;
+        pv[0] = tx - (float)(short)(int)tx;
+        pv[1] = ty - (float)(short)(int)ty;
+        pv[2] = logf(tw / masked.w[a] + 1e-16f);
+        pv[3] = logf(th / masked.h[a] + 1e-16f);
+        pv[4] = sqrtf(2.0f - tw * th / Ff / Ff);
+    }
+    if (t == 0) w.npos[b] = __popcll(om);
+}
+
 __device__ __forceinline__ float bce_term(float o, float t) {
     const float lo = fmaxf(logf(o), -100.f), l1 = fmaxf(logf(1.0f - o), -100.f);
     return -(t * lo + (1.0f - t) * l1);
@@ -388,6 +462,106 @@ __global__ void yolo_dense_targets_kernel(float* __restrict__ target, float* __r
 }
 
 // ------------------------------------------------------------------------------------ postprocess
+// The prediction rows are [5 + C] floats (340 B at C = 80): one thread per row reads 4 B from 64 different lines per
+// load (measured: 25x the tensor's bytes on the fabric, 276 GB/s).  The tiled forms below copy POST_ROWS consecutive rows
+// -- a contiguous span -- into LDS with coalesced loads (row pitch forced odd: conflict-free column walks) and let
+// thread (row, class) pairs read them from there; candidate counts go through an LDS histogram first.
+constexpr int POST_ROWS = 64;
+constexpr int POST_MAX_NCH = 255;                          // 64 rows x 255 floats = 63.8 KB of LDS
+
+__device__ __forceinline__ void post_load_tile(const float* __restrict__ pred, long long row0, int rows, int n_ch,
+                                               int pitch, float* __restrict__ tile) {
+    const float* src = pred + row0 * n_ch;
+    const int total = rows * n_ch;
+    int e = threadIdx.x;
+    int r = e / n_ch, c = e - r * n_ch;
+    const int dr = 256 / n_ch, dc = 256 - dr * n_ch;
+    for (; e < total; e += 256) {
+        tile[r * pitch + c] = src[e];
+        r += dr; c += dc;
+        if (c >= n_ch) { c -= n_ch; ++r; }
+    }
+}
+
+__global__ __launch_bounds__(256) void post_count_tiled_kernel(float* __restrict__ pred, int B, long long N, int C,
+                                                               float conf, int convert, int* __restrict__ counts) {
+    extern __shared__ float post_smem[];
+    const int n_ch = 5 + C, pitch = n_ch | 1;
+    float* tile = post_smem;
+    int* hist = reinterpret_cast<int*>(post_smem + POST_ROWS * pitch);       // [2][C]: the tile's first / second image
+    const long long total = (long long)B * N;
+    const long long ntiles = (total + POST_ROWS - 1) / POST_ROWS;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long row0 = t * POST_ROWS;
+        const int rows = (int)((total - row0) < POST_ROWS ? (total - row0) : POST_ROWS);
+        post_load_tile(pred, row0, rows, n_ch, pitch, tile);
+        for (int i = threadIdx.x; i < 2 * C; i += 256) hist[i] = 0;
+        __syncthreads();
+        const int b0 = (int)(row0 / N);
+        const long long b0_end = (long long)(b0 + 1) * N;                     // rows >= b0_end belong to image b0 + 1 ...
+        if (convert && threadIdx.x < rows) {                                  // utils.py:117-126, written back in place
+            float* q = tile + threadIdx.x * pitch;
+            const float x = q[0], y = q[1], w = q[2], h = q[3];
+            float* p = pred + (row0 + threadIdx.x) * n_ch;
+            p[0] = x - w / 2.f; p[1] = y - h / 2.f; p[2] = x + w / 2.f; p[3] = y + h / 2.f;
+        }
+        for (int e = threadIdx.x; e < POST_ROWS * C; e += 256) {
+            const int r = e & (POST_ROWS - 1), c = e / POST_ROWS;
+            if (r < rows) {
+                const float* q = tile + r * pitch;
+                if (q[5 + c] * q[4] >= conf) {
+                    // ... or a later one when N < POST_ROWS: those go straight to the global counter
+                    const long long i = row0 + r;
+                    if (i < b0_end) atomicAdd(&hist[c], 1);
+                    else if (i < b0_end + N) atomicAdd(&hist[C + c], 1);
+                    else atomicAdd(&counts[(int)(i / N) * C + c], 1);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            const int v = hist[i];
+            const int b = b0 + (i >= C ? 1 : 0);
+            if (v && b < B) atomicAdd(&counts[b * C + (i >= C ? i - C : i)], v);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ unsigned long long make_key(float score, unsigned idx);
+
+__global__ __launch_bounds__(256) void post_fill_tiled_kernel(const float* __restrict__ pred, int B, long long N, int C,
+                                                              float conf, const int* __restrict__ seg_off,
+                                                              int* __restrict__ cursor,
+                                                              unsigned long long* __restrict__ keys) {
+    extern __shared__ float post_smem[];
+    const int n_ch = 5 + C, pitch = n_ch | 1;
+    float* tile = post_smem;
+    const long long total = (long long)B * N;
+    const long long ntiles = (total + POST_ROWS - 1) / POST_ROWS;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long long row0 = t * POST_ROWS;
+        const int rows = (int)((total - row0) < POST_ROWS ? (total - row0) : POST_ROWS);
+        post_load_tile(pred, row0, rows, n_ch, pitch, tile);
+        __syncthreads();
+        for (int e = threadIdx.x; e < POST_ROWS * C; e += 256) {
+            const int r = e & (POST_ROWS - 1), c = e / POST_ROWS;
+            if (r < rows) {
+                const float* q = tile + r * pitch;
+                const float obj = q[4], cc = q[5 + c];
+                if (cc * obj >= conf) {
+                    const long long i = row0 + r;
+                    const int b = (int)(i / N);
+                    const int seg = b * C + c;
+                    const int slot = atomicAdd(&cursor[seg], 1);
+                    keys[seg_off[seg] + slot] = make_key(obj * cc, (unsigned)(i - (long long)b * N));   // utils.py:209
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void post_count_kernel(float* __restrict__ pred, int B, long long N, int C,
                                                          float conf, int convert, int* __restrict__ counts) {
     const long long total = (long long)B * N;
@@ -559,6 +733,8 @@ __device__ int block_greedy_nms(int n, float thresh, int limit, BoxFn box_of, fl
     return kept;
 }
 
+constexpr int NMS_LDS_KEYS = 2048;
+
 __global__ __launch_bounds__(256) void post_nms_kernel(const float* __restrict__ pred, long long N, int C,
                                                        float thresh, const int* __restrict__ seg_off,
                                                        unsigned long long* __restrict__ keys,
@@ -573,7 +749,17 @@ __global__ __launch_bounds__(256) void post_nms_kernel(const float* __restrict__
     const int b = seg / C, c = seg - b * C;
     const int n_ch = 5 + C;
     unsigned long long* k = keys + off;
-    block_bitonic_sort(k, n);
+    if (n <= NMS_LDS_KEYS) {
+        // the usual segment (a few hundred candidates): the bitonic network runs on an LDS copy of the keys
+        __shared__ unsigned long long skeys[NMS_LDS_KEYS];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) skeys[i] = k[i];
+        __syncthreads();
+        block_bitonic_sort(skeys, n);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) k[i] = skeys[i];
+        __syncthreads();
+    } else {
+        block_bitonic_sort(k, n);
+    }
     const float* img = pred + (long long)b * N * n_ch;
     auto box_of = [&](int i) {
         const unsigned idx = (unsigned)(k[i] & 0xffffffffull);
@@ -727,8 +913,13 @@ int y4_yolo_loss_fwd_f32(const float* output, const float* pred, const float* la
     const LossPtrs w = loss_ptrs(workspace, l);
     hipStream_t st = y4_stream(stream);
     if (hipMemsetAsync(w.pos_index, 0xff, (size_t)B * A * F * F * 4, st) != hipSuccess) return Y4_ERR_LAUNCH;
-    hipLaunchKernelGGL(yolo_assign_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, K, B, F, A, n_classes, l.cw,
-                       stride, all, n_all_anchors, anch_mask_host[0], anch_mask_host[1], anch_mask_host[2], masked, w);
+    if (K <= 64) {
+        hipLaunchKernelGGL(yolo_assign_wave_kernel, dim3(B), dim3(64), 0, st, labels, K, B, F, A, n_classes, l.cw,
+                           stride, all, n_all_anchors, anch_mask_host[0], anch_mask_host[1], anch_mask_host[2], masked, w);
+    } else {
+        hipLaunchKernelGGL(yolo_assign_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, K, B, F, A, n_classes, l.cw,
+                           stride, all, n_all_anchors, anch_mask_host[0], anch_mask_host[1], anch_mask_host[2], masked, w);
+    }
     Y4_CHECK_LAUNCH();
     hipLaunchKernelGGL(yolo_loss_dense_kernel, dim3(l.nblocks), dim3(LOSS_BLOCK), 0, st, output, pred, B, F, A, K,
                        n_classes, l.cw, ignore_thresh, obj_mask, w);
@@ -794,8 +985,16 @@ int y4_post_count_f32(float* prediction, int B, long long N, int n_classes, floa
     if (B <= 0 || N <= 0 || n_classes <= 0) return Y4_ERR_SHAPE;
     hipStream_t st = y4_stream(stream);
     if (hipMemsetAsync(counts, 0, (size_t)B * n_classes * 4, st) != hipSuccess) return Y4_ERR_LAUNCH;
-    hipLaunchKernelGGL(post_count_kernel, dim3(grid_for((long long)B * N)), dim3(256), 0, st, prediction, B, N,
-                       n_classes, conf_thre, convert_xyxy, counts);
+    if (5 + n_classes <= POST_MAX_NCH) {
+        const int pitch = (5 + n_classes) | 1;
+        const size_t smem = (size_t)POST_ROWS * pitch * 4 + (size_t)2 * n_classes * 4;
+        const long long ntiles = ((long long)B * N + POST_ROWS - 1) / POST_ROWS;
+        hipLaunchKernelGGL(post_count_tiled_kernel, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(256), smem, st,
+                           prediction, B, N, n_classes, conf_thre, convert_xyxy, counts);
+    } else {
+        hipLaunchKernelGGL(post_count_kernel, dim3(grid_for((long long)B * N)), dim3(256), 0, st, prediction, B, N,
+                           n_classes, conf_thre, convert_xyxy, counts);
+    }
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -818,8 +1017,16 @@ int y4_post_nms_f32(const float* prediction, int B, long long N, int n_classes, 
     int* cursor = reinterpret_cast<int*>(base + l.cursor);
     hipStream_t st = y4_stream(stream);
     if (hipMemsetAsync(cursor, 0, (size_t)nseg * 4, st) != hipSuccess) return Y4_ERR_LAUNCH;
-    hipLaunchKernelGGL(post_fill_kernel, dim3(grid_for((long long)B * N)), dim3(256), 0, st, prediction, B, N,
-                       n_classes, conf_thre, seg_offsets, cursor, keys);
+    if (5 + n_classes <= POST_MAX_NCH) {
+        const int pitch = (5 + n_classes) | 1;
+        const size_t smem = (size_t)POST_ROWS * pitch * 4;
+        const long long ntiles = ((long long)B * N + POST_ROWS - 1) / POST_ROWS;
+        hipLaunchKernelGGL(post_fill_tiled_kernel, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(256), smem, st,
+                           prediction, B, N, n_classes, conf_thre, seg_offsets, cursor, keys);
+    } else {
+        hipLaunchKernelGGL(post_fill_kernel, dim3(grid_for((long long)B * N)), dim3(256), 0, st, prediction, B, N,
+                           n_classes, conf_thre, seg_offsets, cursor, keys);
+    }
     Y4_CHECK_LAUNCH();
     hipLaunchKernelGGL(post_nms_kernel, dim3(nseg), dim3(256), 0, st, prediction, N, n_classes, nms_thre, seg_offsets,
                        keys, reinterpret_cast<float4*>(base + l.kbox), reinterpret_cast<float*>(base + l.karea),

@@ -142,9 +142,35 @@ class BucketedDDP(torch.nn.Module):
                 self._launch(bucket)
         return hook
 
+    # -- measurement aid: when each bucket's exchange is issued relative to the backward pass (bench.py, DESIGN.md section 6)
+    def record_timeline(self, on=True):
+        self._timeline = {'begin': None, 'launch': [], 'end': None} if on else None
+
+    def _mark(self, what, bucket=None):
+        tl = getattr(self, '_timeline', None)
+        if tl is None or not self.buckets or not self.buckets[0].flat.is_cuda:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if what == 'launch':
+            tl['launch'].append((self.buckets.index(bucket), bucket.flat.numel() * bucket.flat.element_size(), ev))
+        else:
+            if what == 'begin':
+                tl['launch'] = []
+            tl[what] = ev
+
+    def timeline(self):
+        """[(bucket index, bytes, ms after the first gradient of the backward pass, ms before its end)] of the last
+        backward pass; events are on the stream the collective is issued from (call after a device synchronize)."""
+        tl = getattr(self, '_timeline', None)
+        if not tl or tl['begin'] is None or tl['end'] is None:
+            return []
+        return [(i, nb, tl['begin'].elapsed_time(ev), ev.elapsed_time(tl['end'])) for i, nb, ev in tl['launch']]
+
     def _begin_backward(self):
         self._in_backward = True
         self._finished = False
+        self._mark('begin')
         try:
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         except RuntimeError:
@@ -156,7 +182,8 @@ class BucketedDDP(torch.nn.Module):
         self.finish_backward()
 
     def _launch(self, b):
-        if b.launched or not self.use_dist:
+        timed = getattr(self, '_timeline', None) is not None
+        if b.launched or not (self.use_dist or timed):
             b.launched = True
             return
         op = dist.ReduceOp.AVG if self.backend == 'nccl' else dist.ReduceOp.SUM
@@ -167,7 +194,9 @@ class BucketedDDP(torch.nn.Module):
             for st in self._producer_streams(b.flat.device):
                 if st != cur:
                     cur.wait_stream(st)
-        b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
+        self._mark('launch', b)               # completes when the bucket's last gradient has landed
+        if self.use_dist:
+            b.work = dist.all_reduce(b.flat, op=op, group=self.pg, async_op=True)
         b.launched = True
 
     @staticmethod
@@ -236,6 +265,7 @@ class BucketedDDP(torch.nn.Module):
         if self.buckets and self.buckets[0].flat.is_cuda:
             from . import ops
             ops.join_side_stream()
+        self._mark('end')
         if self.accumulating:                 # local accumulation only: exchange happens on the last micro-step
             return
         for b in self.buckets:

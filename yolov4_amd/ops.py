@@ -240,6 +240,14 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     return y, mean, invstd
 
 
+def last_conv_kernel():
+    """Symbol (as rocprofv3 prints it) of the conv kernel this thread launched last, '' if unknown; measurement aid."""
+    import ctypes
+    buf = ctypes.create_string_buffer(160)
+    check(lib().y4_last_conv_kernel(buf, 160), 'last_conv_kernel')
+    return buf.value.decode()
+
+
 def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=False):
     L = lib()
     B, Cin, H, W = x_shape
