@@ -265,10 +265,22 @@ def cpu_baseline(size, batch):
             net.forward_eval(x)
             fts.append(time.time() - t0)
     ft = sorted(fts)[1]
+    # configs[0]: the reference's own CPU-runnable case, eval forward of 1x3x416x416
+    x0 = recipe.randn((1, 3, 416, 416), 7)
+    with torch.no_grad():
+        net.forward_eval(x0)
+        f0 = []
+        for _ in range(5):
+            t0 = time.time()
+            net.forward_eval(x0)
+            f0.append(time.time() - t0)
+    f0 = sorted(f0)[2]
     return {'value': batch / dt, 'unit': 'images/sec', 'cores': threads, 'kind': 'port',
             'forward_only_images_per_sec': batch / ft,
+            'config0_416_forward_images_per_sec': 1.0 / f0,
             'sample': f'oracle (torch-CPU fp32 restatement of the reference) on {batch}x3x{size}x{size}: train step '
                       f'fwd+loss+bwd best of 2 after 1 warm-up = {dt:.2f} s; eval forward median of 3 = {ft:.2f} s; '
+                      f'configs[0] eval forward 1x3x416x416 median of 5 = {f0:.3f} s; '
                       f'torch threads {threads}, host cpus {os.cpu_count()}'}
 
 
@@ -512,6 +524,19 @@ def main():
                 f.write(timer.table(args.steps) + '\n')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, args.cpu_batch)
+            # the HIP path on configs[0] beside it (same shape; parity at this shape: tests/test_gpu_round2.py config0 test)
+            model.eval()
+            x0 = recipe.randn((1, 3, 416, 416), 7).to(dev)
+            with torch.no_grad():
+                for _ in range(3):
+                    model(x0)
+                torch.cuda.synchronize(dev)
+                t0 = time.time()
+                for _ in range(20):
+                    model(x0)
+                torch.cuda.synchronize(dev)
+            out['cpu_baseline']['config0_416_forward_images_per_sec_hip'] = 20.0 / (time.time() - t0)
+            model.train()
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -48,7 +48,7 @@ int y4_version(void);
 int y4_device_count(void);
 
 /* Arithmetic of the conv implicit GEMMs (process-wide):
- *   1  "bf16x3" (default): every fp32 operand is split EXACTLY into three bf16 pieces (8+8+8
+ *   1  "bf16x3": every fp32 operand is split EXACTLY into three bf16 pieces (8+8+8
  *      mantissa bits) while its tile is staged into LDS; a product is the six leading terms
  *      a1b1+a1b2+a2b1+a1b3+a2b2+a3b1 on v_mfma_f32_32x32x16_bf16 (products exact, fp32 accumulate).
  *      Dropped terms <= 2^-23 |a*b|: measured error vs an fp64 convolution is at or below that of
@@ -57,7 +57,7 @@ int y4_device_count(void);
  *   2  plain bf16: operands rounded (RN) to bf16 while staged, one bf16 MFMA per product, fp32
  *      accumulate; activations / gradients / BN / loss / NMS stay fp32 (BASELINE config 5, mixed
  *      precision -- NOT fp32-grade: ~3 significant digits per product).
- *   3  "f16x2": every fp32 operand is scaled by a power of two taken from its tensor's max|x| (so the
+ *   3  "f16x2" (default): every fp32 operand is scaled by a power of two taken from its tensor's max|x| (so the
  *      maximum lands in [2^14, 2^15)) and split into two fp16 pieces hi = RN(sx), lo = RN((sx-hi) 2^11)
  *      (11 + 11 significant bits, |error| <= 2^-22 |x|); a product is THREE fp16 MFMAs
  *      (hi*hi -> acc0; hi*lo + lo*hi -> acc1; result (acc0 + 2^-11 acc1)/(s_a s_b)), fp32 accumulate.
