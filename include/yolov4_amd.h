@@ -70,7 +70,9 @@ int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
 /* Scratch arena for library temporaries whose size depends only on the layer (the pre-split filter
  * planes of mode 1: 6 B per filter element, <= 28.3 MB for YOLOv4).  Caller-owned device memory, used
- * in stream order by every conv forward issued afterwards (one stream at a time per process);
+ * in stream order by every conv forward issued afterwards.  ONE arena per process: forward convs must be issued
+ * from one stream of one device at a time (two streams or two devices in one process would race on the planes;
+ * dgrad and wgrad take their plane workspace per call and have no such restriction);
  * stays registered until replaced or reset with (NULL, 0).  Forward convs in mode 1 return
  * Y4_ERR_WORKSPACE when it is missing or too small. */
 int y4_set_workspace(void* ptr, size_t bytes);
@@ -190,7 +192,9 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                          receives that bound and serves as dy_amax of y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 with
                          dy_is_planes = 1 */,
                       void* stream);
-/* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249). workspace: C doubles */
+/* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249): two fixed-order stages, no atomics
+ * (deterministic).  workspace: y4_bias_grad_workspace(M, C) bytes */
+size_t y4_bias_grad_workspace(long long M, int C);
 int y4_bias_grad_f32(const float* dy, int lddy, long long M, int C, float* dbias,
                      void* workspace, size_t workspace_bytes, void* stream);
 /* eval-mode fold (darknet.py:55 in eval): scale = gamma/sqrt(running_var+eps),

@@ -400,20 +400,23 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     if (out_amax && !bounds) amax_commit(amax, out_amax);
 }
 
+// generic column sums (C arbitrary, scalar loads): dbias of the 255-channel head convs.  Two fixed-order stages, no atomics:
+// block r adds rows r, r + R, r + 2R, ... of its column group into part[r][c]; the finalize kernel adds the R partials
+// of a column in index order in fp64.
 __global__ __launch_bounds__(PW_THREADS) void colsum_kernel(const float* __restrict__ x, long long ldx, long long M,
-                                                            int C, double* __restrict__ acc) {
-    // generic column sums (C arbitrary, scalar loads): dbias of the 255-channel head convs
+                                                            int C, float* __restrict__ part) {
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const long long rows_per_block = 256;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
     float s = 0.f;
-    for (long long m = r0; m < r0 + rows_per_block && m < M; ++m) s += x[m * ldx + c];
-    atomicAdd(&acc[c], (double)s);
+    for (long long m = blockIdx.x; m < M; m += gridDim.x) s += x[m * ldx + c];
+    part[(long long)blockIdx.x * C + c] = s;
 }
-__global__ void colsum_finalize_kernel(const double* __restrict__ acc, int C, float* __restrict__ out) {
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ out) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) out[c] = (float)acc[c];
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += (double)part[(long long)r * C + c];
+    out[c] = (float)s;
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -796,18 +799,24 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
     return Y4_OK;
 }
 
+static int colsum_rows(long long M) { return (int)(M < 1024 ? M : 1024); }
+
+size_t y4_bias_grad_workspace(long long M, int C) {
+    if (M <= 0 || C <= 0) return 0;
+    return (size_t)colsum_rows(M) * (size_t)C * sizeof(float);
+}
+
 int y4_bias_grad_f32(const float* dy, int lddy, long long M, int C, float* dbias,
                      void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !dbias || !workspace) return Y4_ERR_NULL;
     if (M <= 0 || C <= 0 || lddy < C) return Y4_ERR_SHAPE;
-    if (workspace_bytes < (size_t)C * sizeof(double)) return Y4_ERR_WORKSPACE;
+    if (workspace_bytes < y4_bias_grad_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
-    double* acc = static_cast<double*>(workspace);
-    if (hipMemsetAsync(acc, 0, (size_t)C * sizeof(double), st) != hipSuccess) return Y4_ERR_LAUNCH;
-    const long long rb = (M + 255) / 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)rb, (C + 255) / 256), dim3(256), 0, st, dy, (long long)lddy, M, C, acc);
+    float* part = static_cast<float*>(workspace);
+    const int R = colsum_rows(M);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)R, (C + 255) / 256), dim3(256), 0, st, dy, (long long)lddy, M, C, part);
     Y4_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, acc, C, dbias);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, R, C, dbias);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

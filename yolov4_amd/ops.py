@@ -370,7 +370,7 @@ def bias_grad_raw(dy):
     B, C, H, W = dy.shape
     dy, ld = as_nhwc(dy, need_vec4=False)
     db = torch.empty(C, device=dy.device, dtype=torch.float32)
-    nbytes = C * 8
+    nbytes = L.y4_bias_grad_workspace(B * H * W, C)
     ws = _ws(nbytes, dy.device)
     check(L.y4_bias_grad_f32(_ptr(dy), ld, B * H * W, C, _ptr(db), _ptr(ws), nbytes, _stream()), 'bias_grad')
     return db
