@@ -94,6 +94,18 @@ int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy
                       const float* scale, const float* shift, int act,
                       const float* residual, int ldr, const unsigned* x_amax /* mode 3, nullable */,
                       unsigned* y_amax /* mode 3, nullable: max|finite y| folded in with atomicMax */, void* stream);
+/* Inference (filters constant between calls), conv mode 3: split a KRSC filter [Cout][K = k*k*Cin] once into the form
+ * the forward kernels consume -- 64-B header (word 0: bit pattern of max|w|; word 1: scratch of the call) followed by the
+ * fp16 hi/lo planes interleaved per 32-deep K tile, y4_conv2d_prepared_bytes(Cout, K) bytes in all -- and run the
+ * forward conv from it: same arithmetic and results as y4_conv2d_fwd_f32, minus its per-call amax + split passes over the
+ * filter.  The prepared buffer is caller-owned and must be refreshed when the filter changes.  (The reference has no
+ * counterpart: nn.Conv2d re-reads its weight every call.) */
+size_t y4_conv2d_prepared_bytes(int Cout, int K);
+int y4_conv2d_prepare_filter_f32(const float* w, int Cout, int K, void* prepared, size_t prepared_bytes, void* stream);
+int y4_conv2d_fwd_prepared_f32(const float* x, int ldx, void* w_prepared, float* y, int ldy,
+                               int B, int H, int W, int Cin, int Cout, int k, int stride,
+                               const float* scale, const float* shift, int act,
+                               const float* residual, int ldr, const unsigned* x_amax, unsigned* y_amax, void* stream);
 /* max |finite element| over the first C channels of an NHWC tensor (pitch ldx), as a bit pattern (mode 3 operand
  * maximum).  y4_amax_f32 overwrites *amax_bits; y4_amax_merge_u32 folds *src into *dst (a concat buffer's maximum is
  * the maximum of its parts).  Integer atomicMax: order independent. */

@@ -530,3 +530,43 @@ def test_engine_train_and_validate_harness(dev):
             assert 0.2 <= r['score'] <= 1.0
     finally:
         _unwrap(ddp)
+
+
+# ------------------------------------------------------------------ inference caches (filter planes, BN fold)
+def test_inference_filter_cache_is_exact_and_expires_with_the_weights(dev):
+    """Under no_grad an eval-mode ConvBNAct splits its filter once per parameter version (y4_conv2d_prepare_filter_f32)
+    and folds its BatchNorm once: results must be bit-identical to the per-call path, and both caches must expire when
+    the weights or running statistics are rewritten behind torch's back (fused optimizer step, training forward)."""
+    from yolov4_amd import ops
+    from yolov4_amd.darknet.darknet import ConvBNAct
+    from yolov4_amd.yolo.optim.optimizers.build import FusedAdam
+    torch.manual_seed(3)
+    m = ConvBNAct(64, 128, 3, 1, act='mish').to(dev)
+    x = torch.randn(2, 64, 20, 20, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def uncached():
+        m.eval()
+        with torch.enable_grad():                      # grad mode on: the per-call path (amax + split inside the call)
+            return m(x).detach().clone()
+
+    def cached():
+        m.eval()
+        with torch.no_grad():
+            return m(x).clone()
+    a, b = uncached(), cached()
+    assert getattr(m.conv.weight, '_y4_prepared', None) is not None, 'the prepared-filter path did not run'
+    assert torch.equal(a, b)
+    assert torch.equal(cached(), b)                    # second call: served from the cache
+    # a training forward rewrites running_mean / running_var through raw pointers
+    m.train()
+    m(x)
+    assert torch.equal(uncached(), cached())
+    # a fused optimizer step rewrites the filter through raw pointers
+    opt = FusedAdam([p for p in m.parameters()], lr=1e-2)
+    m.train()
+    m(x).square().mean().backward()
+    before = cached()
+    opt.step()
+    after_u, after_c = uncached(), cached()
+    assert torch.equal(after_u, after_c)
+    assert not torch.equal(before, after_c)

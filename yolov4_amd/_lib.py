@@ -32,6 +32,9 @@ PROTOTYPES = {
     'y4_set_workspace': (I, [P, Z]),
     'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P, P]),
     'y4_amax_f32': (I, [P, I, L, I, P, P]),
+    'y4_conv2d_prepared_bytes': (Z, [I, I]),
+    'y4_conv2d_prepare_filter_f32': (I, [P, I, I, P, Z, P]),
+    'y4_conv2d_fwd_prepared_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P, P]),
     'y4_amax_merge_u32': (I, [P, P, P]),
     'y4_last_conv_kernel': (I, [ctypes.c_char_p, I]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),

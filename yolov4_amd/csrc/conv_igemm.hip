@@ -1755,8 +1755,8 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
                          const float* scale, const float* shift, int act,
                          const float* residual, int ldr, float* stats, int* nparts, const unsigned* x_amax,
-                         unsigned* y_amax, void* stream) {
-    if (!x || !w || !y) return Y4_ERR_NULL;
+                         unsigned* y_amax, void* stream, void* w_prepared = nullptr) {
+    if (!x || (!w && !w_prepared) || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
     if (Cin <= 0 || Cin % BK != 0 || ldx < Cin || ldy < Cout || (ldx & 3) || (residual && ldr < Cout))
@@ -1773,6 +1773,20 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
     const long long M = (long long)B * g.Hd * g.Wd;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cin; g.act = act;
+    if (w_prepared) {
+        // filter already split (y4_conv2d_prepare_filter_f32): [word 0: max|w| bits][word 1: scratch][.. 64 B][planes]
+        if (g_conv_mode != 3) return Y4_ERR_SHAPE;
+        if (reinterpret_cast<uintptr_t>(w_prepared) & 15) return Y4_ERR_SHAPE;
+        unsigned* hdr = static_cast<unsigned*>(w_prepared);
+        g.wt_planes = reinterpret_cast<unsigned short*>(static_cast<char*>(w_prepared) + 64);
+        if (!x_amax) {
+            const int rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, hdr + 1, y4_stream(stream));
+            if (rc != Y4_OK) return rc;
+            x_amax = hdr + 1;
+        }
+        g.src_amax = x_amax; g.wt_amax = hdr; g.dst_amax = y_amax;
+        return y4::f16x2_gather(g, false, y4_stream(stream), nparts);
+    }
     if (g_conv_mode != 0) {
         const long long nw = (long long)Cout * g.K;
         if (!g_scratch || g_scratch_bytes < SCRATCH_HDR + (size_t)nw * 6) return Y4_ERR_WORKSPACE;   // y4_set_workspace() first
@@ -1921,6 +1935,32 @@ int y4_last_conv_kernel(char* buf, int cap) {
     snprintf(buf, (size_t)cap, "%s", g_last_kernel);
     g_last_kernel[0] = 0;
     return Y4_OK;
+}
+
+size_t y4_conv2d_prepared_bytes(int Cout, int K) {
+    if (Cout <= 0 || K <= 0) return 0;
+    return 64 + (size_t)Cout * (size_t)K * 4;
+}
+
+int y4_conv2d_prepare_filter_f32(const float* w, int Cout, int K, void* prepared, size_t prepared_bytes, void* stream) {
+    if (!w || !prepared) return Y4_ERR_NULL;
+    if (Cout <= 0 || K <= 0 || (K & 31)) return Y4_ERR_SHAPE;
+    if (prepared_bytes < y4_conv2d_prepared_bytes(Cout, K)) return Y4_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(prepared) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) return Y4_ERR_SHAPE;
+    unsigned* hdr = static_cast<unsigned*>(prepared);
+    int rc = y4::amax_launch(w, K, Cout, K, hdr, y4_stream(stream));
+    if (rc != Y4_OK) return rc;
+    return y4::f16x2_split_filter(w, reinterpret_cast<unsigned short*>(static_cast<char*>(prepared) + 64),
+                                  (long long)Cout * K, hdr, y4_stream(stream));
+}
+
+int y4_conv2d_fwd_prepared_f32(const float* x, int ldx, void* w_prepared, float* y, int ldy,
+                               int B, int H, int W, int Cin, int Cout, int k, int stride,
+                               const float* scale, const float* shift, int act,
+                               const float* residual, int ldr, const unsigned* x_amax, unsigned* y_amax, void* stream) {
+    if (!w_prepared) return Y4_ERR_NULL;
+    return conv_fwd_impl(x, ldx, nullptr, y, ldy, B, H, W, Cin, Cout, k, stride, scale, shift, act, residual, ldr, nullptr,
+                         nullptr, x_amax, y_amax, stream, w_prepared);
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {

@@ -176,8 +176,35 @@ def conv_out_hw(H, W, k, s):
 
 
 # ------------------------------------------------------------------ raw op wrappers (no autograd)
+# Kernels of this library write parameters (fused optimizers) and BatchNorm running statistics (training forward) through
+# raw pointers, which torch's version counters do not see: every such write bumps this epoch, and the inference caches
+# below key on it.
+WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    WEIGHTS_EPOCH[0] += 1
+
+
+def prepared_filter(param):
+    """Inference only (conv mode 3): the filter's maximum + fp16 planes, split once per parameter version and kept on the
+    parameter (y4_conv2d_prepare_filter_f32) instead of once per forward call."""
+    w = krsc(param)
+    key = (WEIGHTS_EPOCH[0], param._version, w.data_ptr())
+    hit = getattr(param, '_y4_prepared', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    L = lib()
+    Cout, K = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
+    nbytes = L.y4_conv2d_prepared_bytes(Cout, K)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(L.y4_conv2d_prepare_filter_f32(_ptr(w), Cout, K, _ptr(buf), nbytes, _stream()), 'conv2d_prepare_filter')
+    param._y4_prepared = (key, buf)
+    return buf
+
+
 def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
-                 out_amax=None):
+                 out_amax=None, w_prepared=None):
     L = lib()
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -198,6 +225,11 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
+    if w_prepared is not None:
+        check(L.y4_conv2d_fwd_prepared_f32(_ptr(x), ldx, _ptr(w_prepared), _ptr(out), ldy, B, H, W, Cin, Cout, k, s,
+                                           _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _ptr(x_amax),
+                                           _ptr(out_amax), _stream()), 'conv2d_fwd_prepared')
+        return out
     check(L.y4_conv2d_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, B, H, W, Cin, Cout, k, s,
                               _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _ptr(x_amax), _ptr(out_amax),
                               _stream()), 'conv2d_fwd')
@@ -237,6 +269,8 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     check(L.y4_bn_finalize_partials_f32(_ptr(part), nparts, B * Ho * Wo, Cout, _ptr(mean), _ptr(invstd),
                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), float(momentum), float(eps),
                                         _ptr(ws), wsb, _stream()), 'bn_finalize_partials')
+    if running_mean is not None:
+        bump_weights_epoch()                   # running statistics written behind torch's back
     return y, mean, invstd
 
 
@@ -376,6 +410,20 @@ def bias_grad_raw(dy):
     return db
 
 
+def bn_fold_cached(gamma, beta, rm, rv, eps):
+    """Inference only: the folded (scale, shift) of an eval-mode BatchNorm, recomputed when any of its four tensors changes."""
+    key = (WEIGHTS_EPOCH[0], gamma._version, beta._version, rm._version, rv._version, gamma.data_ptr(), rm.data_ptr(), float(eps))
+    hit = getattr(gamma, '_y4_fold', None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    val = bn_fold_raw(gamma, beta, rm, rv, eps)
+    try:
+        gamma._y4_fold = (key, val)
+    except AttributeError:
+        pass
+    return val
+
+
 def bn_fold_raw(gamma, beta, rm, rv, eps):
     L = lib()
     C = gamma.numel()
@@ -503,16 +551,23 @@ class ConvBNActFn(torch.autograd.Function):
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
         elif bn:
-            scale, shift = bn_fold_raw(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
+            # no autograd in flight (val.py / detect.py): the filter planes and the BN fold are per-parameter-version caches
+            frozen = not torch.is_grad_enabled()
+            wprep = prepared_filter(cfg['weight_param']) if (frozen and f16 and cfg.get('weight_param') is not None) else None
+            fold = bn_fold_cached if frozen else bn_fold_raw
+            scale, shift = fold(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
             o = dest
             Ho, Wo = conv_out_hw(x.shape[2], x.shape[3], k, s)
             o = o if _slot_ok(o, (x.shape[0], weight.shape[0], Ho, Wo)) else None
             if f16:
                 z_amax = (cfg.get('out_amax') if o is not None else None) or new_amax(x.device)
-            z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual, out=o, x_amax=x_amax, out_amax=z_amax)
+            z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual, out=o, x_amax=x_amax, out_amax=z_amax,
+                             w_prepared=wprep)
             ctx.mode = 'bn_eval'
         else:
-            z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32, x_amax=x_amax)
+            wprep = prepared_filter(cfg['weight_param']) if (not torch.is_grad_enabled() and f16
+                                                              and cfg.get('weight_param') is not None) else None
+            z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32, x_amax=x_amax, w_prepared=wprep)
             if act != 'linear':
                 ctx.mode = 'nobn_act'
             else:
