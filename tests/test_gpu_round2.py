@@ -570,3 +570,9 @@ def test_inference_filter_cache_is_exact_and_expires_with_the_weights(dev):
     after_u, after_c = uncached(), cached()
     assert torch.equal(after_u, after_c)
     assert not torch.equal(before, after_c)
+
+
+def test_graft_entry_smoke_runs(dev):
+    """The driver's smoke() (one tiny train step + eval + NMS against the oracle) must pass on this build."""
+    import __graft_entry__ as g
+    g.smoke()

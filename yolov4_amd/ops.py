@@ -552,7 +552,7 @@ class ConvBNActFn(torch.autograd.Function):
             ctx.mode = 'bn_train'
         elif bn:
             # no autograd in flight (val.py / detect.py): the filter planes and the BN fold are per-parameter-version caches
-            frozen = not torch.is_grad_enabled()
+            frozen = not torch.is_grad_enabled() and os.environ.get('Y4_NO_INFER_CACHE') != '1'
             wprep = prepared_filter(cfg['weight_param']) if (frozen and f16 and cfg.get('weight_param') is not None) else None
             fold = bn_fold_cached if frozen else bn_fold_raw
             scale, shift = fold(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
@@ -565,7 +565,7 @@ class ConvBNActFn(torch.autograd.Function):
                              w_prepared=wprep)
             ctx.mode = 'bn_eval'
         else:
-            wprep = prepared_filter(cfg['weight_param']) if (not torch.is_grad_enabled() and f16
+            wprep = prepared_filter(cfg['weight_param']) if (not torch.is_grad_enabled() and f16 and os.environ.get('Y4_NO_INFER_CACHE') != '1'
                                                               and cfg.get('weight_param') is not None) else None
             z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32, x_amax=x_amax, w_prepared=wprep)
             if act != 'linear':
