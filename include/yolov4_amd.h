@@ -148,6 +148,21 @@ int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, in
                            halfs][Cout lo halfs]; needs dy_amax = its word [5], lddy == Cout, Cout % 32 == 0 */,
                         const float* residual, int ldr, void* stream);
 
+/* y4_conv2d_dgrad_f32 for a 3x3 stride-1 conv (conv mode 3) whose input is the output of exactly one BatchNorm+act layer:
+ * dx is that layer's dz, so the epilogue also takes the layer's BatchNorm-backward column sums per tile -- it reads the
+ * layer's pre-BN tensor bn_y [B*H*W][bn_ld] (same pixels / channels as dx) and its mean / invstd / gamma / beta -- and
+ * writes them to bn_partials ([*n_partials_host][2][Cin], y4_conv2d_dgrad_bnfold_partials() bytes) for
+ * y4_bn_act_bwd_presummed_f32.  Autograd of darknet/darknet.py:53-56 as y4_conv2d_dgrad_f32 + y4_bn_act_bwd_f32, minus one
+ * read sweep over dz and y. */
+size_t y4_conv2d_dgrad_bnfold_partials(int B, int H, int W, int Cin);
+int y4_conv2d_dgrad_bnfold_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                               int B, int H, int W, int Cin, int Cout, int k, int stride,
+                               void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
+                               const float* residual, int ldr,
+                               const float* bn_y, int bn_ld, const float* bn_mean, const float* bn_invstd,
+                               const float* bn_gamma, const float* bn_beta, int bn_act,
+                               float* bn_partials, size_t bn_partials_bytes, int* n_partials_host, void* stream);
+
 /* wgrad: dw[Cout][k][k][Cin] = sum_{b,ho,wo} dy (x) x -- autograd of nn.Conv2d wrt weight.
  * Split-K over pixels into fp32 slabs in `workspace`, reduced in a fixed order (deterministic). */
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride);
@@ -204,6 +219,14 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                          receives that bound and serves as dy_amax of y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 with
                          dy_is_planes = 1 */,
                       void* stream);
+/* BatchNorm backward whose two column sums (sum g, sum g*xhat with g = dz * act'(gamma*xhat+beta)) were already taken
+ * per tile by the dgrad kernel that produced dz (y4_conv2d_dgrad_bnfold_f32): the reduce sweep over dz and y is skipped,
+ * everything else is y4_bn_act_bwd_f32.  partials: [n_partials][2][C] fp32. */
+int y4_bn_act_bwd_presummed_f32(const float* dz, int lddz, const float* y, int ldy,
+                                const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                int act, float* dy, int lddy, float* dgamma, float* dbeta,
+                                long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
+                                const float* partials, int n_partials, void* stream);
 /* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249): two fixed-order stages, no atomics
  * (deterministic).  workspace: y4_bias_grad_workspace(M, C) bytes */
 size_t y4_bias_grad_workspace(long long M, int C);

@@ -576,3 +576,49 @@ def test_graft_entry_smoke_runs(dev):
     """The driver's smoke() (one tiny train step + eval + NMS against the oracle) must pass on this build."""
     import __graft_entry__ as g
     g.smoke()
+
+
+# ------------------------------------------------------------------ BatchNorm-backward sums folded into the consumer's dgrad
+def test_bn_backward_fold_matches_the_sweep_and_falls_back_when_unsafe(dev):
+    """A 3x3 stride-1 conv that is the SOLE consumer of a BatchNorm+act output takes that layer's backward column sums in
+    its dgrad epilogue (y4_conv2d_dgrad_bnfold_f32 -> y4_bn_act_bwd_presummed_f32).  Gradients must agree with the
+    reduce-sweep path to fp32 summation-order accuracy; a tensor consumed twice must fall back to the sweep."""
+    from yolov4_amd import ops
+    from yolov4_amd.darknet.darknet import ConvBNAct
+    torch.manual_seed(11)
+    a = ConvBNAct(64, 64, 1, 1, act='mish').to(dev).train()
+    b = ConvBNAct(64, 128, 3, 1, act='mish').to(dev).train()
+    c = ConvBNAct(64, 64, 3, 1, act='leaky_relu').to(dev).train()
+    x = torch.randn(4, 64, 38, 38, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(4, 128, 38, 38, device=dev).contiguous(memory_format=torch.channels_last)
+
+    was_on = ops.BN_FOLD['on']
+
+    def run(fold, twice):
+        ops.BN_FOLD['on'] = fold
+        for m in (a, b, c):
+            m.zero_grad(set_to_none=True)
+        x.grad = None
+        f0, s0 = ops.BN_FOLD['folded'], ops.BN_FOLD['swept']
+        z = a(x)
+        loss = (b(z) * w).sum()
+        if twice:
+            loss = loss + c(z).square().sum()          # second consumer of z WITHOUT ops.fork: autograd accumulates
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = [p.grad.clone() for m in (a, b) for p in m.parameters()] + [x.grad.clone()]
+        return grads, ops.BN_FOLD['folded'] - f0, ops.BN_FOLD['swept'] - s0
+    try:
+        ref, f, s = run(False, False)
+        assert f == 0 and s == 2
+        got, f, s = run(True, False)
+        assert f == 1 and s == 1, (f, s)              # a's BatchNorm folded into b's dgrad; b's own BN is swept
+        for g, r in zip(got, ref):
+            assert torch.allclose(g, r, rtol=2e-4, atol=2e-5 * float(r.abs().max())), float((g - r).abs().max() / r.abs().max())
+        ref2, f, s = run(False, True)
+        got2, f, s = run(True, True)
+        assert f == 0, 'a doubly consumed tensor must not use deposited sums'
+        for g, r in zip(got2, ref2):
+            assert torch.allclose(g, r, rtol=2e-4, atol=2e-5 * float(r.abs().max()))
+    finally:
+        ops.BN_FOLD['on'] = was_on

@@ -52,6 +52,10 @@ PROTOTYPES = {
     'y4_bn_stats_f32': (I, [P, I, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, P]),
     'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, P]),
+    'y4_bn_act_bwd_presummed_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, I, P]),
+    'y4_conv2d_dgrad_bnfold_partials': (Z, [I, I, I, I]),
+    'y4_conv2d_dgrad_bnfold_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, I,
+                                       P, I, P, P, P, P, I, P, Z, ctypes.POINTER(ctypes.c_int), P]),
     'y4_bias_grad_workspace': (Z, [L, I]),
     'y4_bias_grad_f32': (I, [P, I, L, I, P, P, Z, P]),
     'y4_bn_fold_f32': (I, [P, P, P, P, F, P, P, I, P]),

@@ -432,6 +432,10 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         const bool nok = n < g.N;
         const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
         const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
+        float bn_mu = 0.f, bn_is = 0.f, bn_ga = 0.f, bn_be = 0.f;
+        if constexpr (TRANSPOSED) {
+            if (g.bn_part && nok) { bn_mu = g.bn_mean[n]; bn_is = g.bn_invstd[n]; bn_ga = g.bn_gamma[n]; bn_be = g.bn_beta[n]; }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             // the skip / fan-in operand of this tile column is fetched as one batch BEFORE the stores (the compiler may
@@ -444,11 +448,18 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                 mm[e] = row_m[wm * WTM + i * MS + rl];
                 rr[e] = (g.res && nok && mm[e] >= 0) ? g.res[(long long)mm[e] * g.ldr + n] : 0.f;
             }
+            float yy[ACCN];                                // BN-backward fold: the producer's pre-BN values of these cells
+            if constexpr (TRANSPOSED) {
+#pragma unroll
+                for (int e = 0; e < ACCN; ++e)
+                    yy[e] = (g.bn_part && nok && mm[e] >= 0) ? g.bn_y[(long long)mm[e] * g.bn_ld + n] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
                 const float raw = acc0[i][j][e] * un + acc1[i][j][e] * un1;
                 acc0[i][j][e] = raw;                       // kept for the BN statistics below
                 const int m = mm[e];
+                float gg = 0.f, gx = 0.f;
                 if (nok && m >= 0) {
                     float v = raw * sc + sh;
                     v = y4_act(v, g.act);
@@ -456,6 +467,16 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     g.dst[(long long)m * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                    if constexpr (TRANSPOSED) {
+                        if (g.bn_part) {
+                            const float xh = (yy[e] - bn_mu) * bn_is;
+                            gg = v * y4_act_grad(bn_ga * xh + bn_be, g.bn_act);
+                            gx = gg * xh;
+                        }
+                    }
+                }
+                if constexpr (TRANSPOSED) {
+                    if (g.bn_part) { acc0[i][j][e] = gg; acc1[i][j][e] = gx; }
                 }
             }
         }
@@ -468,7 +489,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         }
         if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
     }
-    if (!TRANSPOSED && g.stats) {
+    float* const colsums = TRANSPOSED ? g.bn_part : g.stats;      // forward: BN statistics; dgrad: BN-backward sums
+    if (colsums) {
         float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the K loop ended with a barrier
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -476,7 +498,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < ACCN; ++e) { const float v = acc0[i][j][e]; cs += v; css += v * v; }
+                for (int e = 0; e < ACCN; ++e) {
+                    const float v = acc0[i][j][e];
+                    cs += v;
+                    css += TRANSPOSED ? acc1[i][j][e] : v * v;
+                }
             if constexpr (MS == 16) {
                 cs += __shfl_xor(cs, 16, 64);
                 css += __shfl_xor(css, 16, 64);
@@ -496,8 +522,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
             for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
             const int n = n0 + c;
             if (n < g.N) {
-                g.stats[((long long)mt_local * 2 + 0) * g.N + n] = cs;
-                g.stats[((long long)mt_local * 2 + 1) * g.N + n] = css;
+                colsums[((long long)mt_local * 2 + 0) * g.N + n] = cs;
+                colsums[((long long)mt_local * 2 + 1) * g.N + n] = css;
             }
         }
     }
@@ -963,13 +989,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
         const bool nok = n < g.N;
         const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
         const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
+        float bn_mu = 0.f, bn_is = 0.f, bn_ga = 0.f, bn_be = 0.f;
+        if constexpr (TRANSPOSED) {
+            if (g.bn_part && nok) { bn_mu = g.bn_mean[n]; bn_is = g.bn_invstd[n]; bn_ga = g.bn_gamma[n]; bn_be = g.bn_beta[n]; }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float rr[ACCN];
+            float rr[ACCN], yy[ACCN];
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
                 const int rl = wm * WTM + i * MS + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
                 rr[e] = (g.res && nok && rl < cnt) ? g.res[(mbase + rl) * g.ldr + n] : 0.f;
+                if constexpr (TRANSPOSED) yy[e] = (g.bn_part && nok && rl < cnt) ? g.bn_y[(mbase + rl) * g.bn_ld + n] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
@@ -977,6 +1008,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
                 const bool rok = rl < cnt;
                 const float raw = rok ? acc0[i][j][e] * un + acc1[i][j][e] * un1 : 0.f;
                 acc0[i][j][e] = raw;                       // kept for the BN statistics below (0 for rows past the image)
+                float gg = 0.f, gx = 0.f;
                 if (nok && rok) {
                     float v = raw * sc + sh;
                     v = y4_act(v, g.act);
@@ -984,6 +1016,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
                     g.dst[(mbase + rl) * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                    if constexpr (TRANSPOSED) {
+                        if (g.bn_part) {                   // BN-backward fold (see the gather kernel)
+                            const float xh = (yy[e] - bn_mu) * bn_is;
+                            gg = v * y4_act_grad(bn_ga * xh + bn_be, g.bn_act);
+                            gx = gg * xh;
+                        }
+                    }
+                }
+                if constexpr (TRANSPOSED) {
+                    if (g.bn_part) { acc0[i][j][e] = gg; acc1[i][j][e] = gx; }
                 }
             }
         }
@@ -996,7 +1038,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
         }
         if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
     }
-    if (!TRANSPOSED && g.stats) {
+    float* const colsums = TRANSPOSED ? g.bn_part : g.stats;      // forward: BN statistics; dgrad: BN-backward sums
+    if (colsums) {
         float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the step loop ended with a barrier
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1004,7 +1047,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < ACCN; ++e) { const float v = acc0[i][j][e]; cs += v; css += v * v; }
+                for (int e = 0; e < ACCN; ++e) {
+                    const float v = acc0[i][j][e];
+                    cs += v;
+                    css += TRANSPOSED ? acc1[i][j][e] : v * v;
+                }
             if constexpr (MS == 16) {
                 cs += __shfl_xor(cs, 16, 64);
                 css += __shfl_xor(css, 16, 64);
@@ -1024,8 +1071,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
             for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
             const int n = n0 + c;
             if (n < g.N) {
-                g.stats[((long long)mt * 2 + 0) * g.N + n] = cs;
-                g.stats[((long long)mt * 2 + 1) * g.N + n] = css;
+                colsums[((long long)mt * 2 + 0) * g.N + n] = cs;
+                colsums[((long long)mt * 2 + 1) * g.N + n] = css;
             }
         }
     }

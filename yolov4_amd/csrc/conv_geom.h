@@ -33,6 +33,15 @@ struct ConvGeom {
     // into [2^14, 2^15) before it is split into fp16 pieces, and the epilogue undoes both scales
     const unsigned* src_amax; const unsigned* wt_amax;
     unsigned* dst_amax;           // f16x2 forward, optional: max|finite output| folded in with atomicMax
+    // dgrad only: fold the BatchNorm-backward reduction of the layer whose output gradient this launch produces into the
+    // epilogue (the per-tile column sums of g = dx * act'(u) and g * xhat, u = gamma * xhat + beta, xhat = (y - mean) * invstd)
+    const float* bn_y;            // that layer's pre-BN tensor [M][bn_ld], same pixels / channels as dst
+    const float* bn_mean;
+    const float* bn_invstd;
+    const float* bn_gamma;
+    const float* bn_beta;
+    float* bn_part;               // [tiles][2][N] partial sums (nullptr: no fold)
+    int bn_ld, bn_act;
     int stagger;                  // > 0: blocks in an odd wave slot start their K loop 64*stagger cycles late (see conv_f16x2.hip)
     unsigned long long* stamps;   // diagnostic builds only (Y4_STAMPS): cycle sums per loop segment
     int src_planes;               // f16x2: the gathered tensor is already split: per pixel [Cs hi halfs][Cs lo halfs] (4 Cs bytes)

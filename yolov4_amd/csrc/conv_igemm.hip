@@ -1864,10 +1864,17 @@ size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
     return (size_t)Cin * k * k * cp * 6 + 64;
 }
 
+struct BnFold {                                            // see ConvGeom::bn_*
+    const float *y, *mean, *invstd, *gamma, *beta;
+    int ld, act;
+    float* part;
+    int* nparts;
+};
+
 static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx, int lddx,
                            int B, int H, int W, int Cin, int Cout, int k, int stride,
                            void* workspace, size_t workspace_bytes, const unsigned* dy_amax, int dy_is_planes,
-                           const float* residual, int ldr, void* stream) {
+                           const float* residual, int ldr, void* stream, const BnFold* fold = nullptr) {
     if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1917,7 +1924,11 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
         }
         g.src_amax = dy_amax; g.wt_amax = hdr;
         if (g_scratch && g_scratch_bytes >= SCRATCH_HDR) g.stamps = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(g_scratch) + 16);
-        return y4::f16x2_gather(g, true, st, nullptr);
+        if (fold) {
+            g.bn_y = fold->y; g.bn_ld = fold->ld; g.bn_mean = fold->mean; g.bn_invstd = fold->invstd;
+            g.bn_gamma = fold->gamma; g.bn_beta = fold->beta; g.bn_act = fold->act; g.bn_part = fold->part;
+        }
+        return y4::f16x2_gather(g, true, st, fold ? fold->nparts : nullptr);
     }
     return dispatch_gather<true>(g, st);
 }
@@ -1961,6 +1972,34 @@ int y4_conv2d_fwd_prepared_f32(const float* x, int ldx, void* w_prepared, float*
     if (!w_prepared) return Y4_ERR_NULL;
     return conv_fwd_impl(x, ldx, nullptr, y, ldy, B, H, W, Cin, Cout, k, stride, scale, shift, act, residual, ldr, nullptr,
                          nullptr, x_amax, y_amax, stream, w_prepared);
+}
+
+size_t y4_conv2d_dgrad_bnfold_partials(int B, int H, int W, int Cin) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return 0;
+    const long long M = (long long)B * H * W;
+    long long rows = (M + 63) / 64;
+    const long long per_img = (long long)B * (((long long)H * W + 127) / 128);
+    if (per_img > rows) rows = per_img;
+    return (size_t)rows * 2 * (size_t)Cin * sizeof(float);
+}
+
+int y4_conv2d_dgrad_bnfold_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                               int B, int H, int W, int Cin, int Cout, int k, int stride,
+                               void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
+                               const float* residual, int ldr,
+                               const float* bn_y, int bn_ld, const float* bn_mean, const float* bn_invstd,
+                               const float* bn_gamma, const float* bn_beta, int bn_act,
+                               float* bn_partials, size_t bn_partials_bytes, int* n_partials_host, void* stream) {
+    if (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || !bn_partials || !n_partials_host) return Y4_ERR_NULL;
+    // the fold lives in the epilogues of the 3x3 stride-1 f16x2 dgrad kernels (long K loops: the epilogue is cheap there)
+    if (g_conv_mode != 3 || k != 3 || stride != 1 || bn_ld < Cin) return Y4_ERR_SHAPE;
+    if (bn_partials_bytes < y4_conv2d_dgrad_bnfold_partials(B, H, W, Cin)) return Y4_ERR_WORKSPACE;
+    int nparts = 0;
+    const BnFold f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_ld, bn_act, bn_partials, &nparts};
+    const int rc = conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, dy_amax,
+                                   0, residual, ldr, stream, &f);
+    *n_partials_host = nparts;
+    return rc;
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {

@@ -282,7 +282,16 @@ def last_conv_kernel():
     return buf.value.decode()
 
 
-def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=False):
+# BatchNorm-backward column sums taken in the epilogue of the consuming 3x3 dgrad instead of by the reduce sweep.  Built,
+# parity-tested, and measured +-0 on the training step (34 of 107 layers qualify -- the 1x1 convs inside ResBlock units and
+# conv sets; their reduce sweeps cost 1.5 ms, the Mish' work in the issue-bound dgrad epilogues costs the same): opt-in.
+BN_FOLD = {'on': os.environ.get('Y4_BN_FOLD', '0') == '1', 'folded': 0, 'swept': 0}
+
+
+def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=False, bn_fold=None):
+    """bn_fold: the producer box of the BatchNorm+act layer whose output this conv consumed alone (ConvBNActFn.forward):
+    the kernel then also takes that layer's BatchNorm-backward column sums in its epilogue and the call returns
+    (dx, partials, n_partials)."""
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
@@ -294,6 +303,17 @@ def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
+    if bn_fold is not None:
+        by, bld = as_nhwc(bn_fold['y'])
+        pbytes = L.y4_conv2d_dgrad_bnfold_partials(B, H, W, Cin)
+        part = torch.empty(pbytes // 4, dtype=torch.float32, device=dy.device)
+        n = ctypes.c_int(0)
+        check(L.y4_conv2d_dgrad_bnfold_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
+                                           _ptr(ws), nbytes, _ptr(dy_amax), _ptr(residual), ldr,
+                                           _ptr(by), bld, _ptr(bn_fold['mean']), _ptr(bn_fold['invstd']),
+                                           _ptr(bn_fold['gamma']), _ptr(bn_fold['beta']), ACT_IDS[bn_fold['act']],
+                                           _ptr(part), pbytes, ctypes.byref(n), _stream()), 'conv2d_dgrad_bnfold')
+        return dx, part, n.value
     check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
                                 _ptr(ws), nbytes, _ptr(dy_amax), 1 if dy_planes else 0, _ptr(residual), ldr, _stream()),
           'conv2d_dgrad')
@@ -379,7 +399,8 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
     return z
 
 
-def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None):
+def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None,
+                   pre=None):
     """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
     L = lib()
     B, C, H, W = y.shape
@@ -393,6 +414,12 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
     dgamma, dbeta = slot(dgamma_out), slot(dbeta_out)
     nbytes = L.y4_bn_workspace(B * H * W, C)
     ws = _ws(nbytes, y.device)
+    if pre is not None:                       # (partials, n): column sums already taken by the dgrad that produced dz
+        check(L.y4_bn_act_bwd_presummed_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
+                                            ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
+                                            _ptr(ws), nbytes, _ptr(out_amax), _ptr(pre[0]), int(pre[1]), _stream()),
+              'bn_act_bwd_presummed')
+        return dy, dgamma, dbeta
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
                               _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), _stream()), 'bn_act_bwd')
@@ -532,6 +559,14 @@ class ConvBNActFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         # conv mode 3: operand maxima travel with the tensors (see "operand maxima" above)
         f16 = f16x2_mode() and x.shape[1] != 3
+        # BatchNorm-backward fold: x is the untouched output of ONE BatchNorm+act layer (its producer box rides on the
+        # tensor) and this is a 3x3 stride-1 conv: the dgrad epilogue will take that layer's column sums (backward below)
+        src = cfg.get('bn_src')
+        ctx.bn_src = None
+        if (src is not None and BN_FOLD['on'] and f16 and k == 3 and s == 1 and bn and training and cfg.get('grad', True)
+                and not DY_PLANES['dgrad'] and x.data_ptr() == src[1] and tuple(x.shape) == src[2] and x.stride() == src[3]):
+            ctx.bn_src = src[0]
+        ctx.bn_box = None
         x_amax = cfg.get('x_amax') if f16 else None
         z_amax = None
         io = cfg.get('io')
@@ -550,9 +585,14 @@ class ConvBNActFn(torch.autograd.Function):
             z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
+            if io is not None and cfg.get('grad', True):
+                # producer box: what a sole 3x3 consumer needs to take this layer's BatchNorm-backward sums for it
+                ctx.bn_box = {'y': y, 'mean': mean, 'invstd': invstd, 'gamma': gamma.detach(), 'beta': beta.detach(),
+                              'act': act, 'slot': {}}
+                io['bn_src'] = ctx.bn_box
         elif bn:
             # no autograd in flight (val.py / detect.py): the filter planes and the BN fold are per-parameter-version caches
-            frozen = not torch.is_grad_enabled() and os.environ.get('Y4_NO_INFER_CACHE') != '1'
+            frozen = not cfg.get('grad', True) and os.environ.get('Y4_NO_INFER_CACHE') != '1'
             wprep = prepared_filter(cfg['weight_param']) if (frozen and f16 and cfg.get('weight_param') is not None) else None
             fold = bn_fold_cached if frozen else bn_fold_raw
             scale, shift = fold(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
@@ -565,7 +605,7 @@ class ConvBNActFn(torch.autograd.Function):
                              w_prepared=wprep)
             ctx.mode = 'bn_eval'
         else:
-            wprep = prepared_filter(cfg['weight_param']) if (not torch.is_grad_enabled() and f16 and os.environ.get('Y4_NO_INFER_CACHE') != '1'
+            wprep = prepared_filter(cfg['weight_param']) if (not cfg.get('grad', True) and f16 and os.environ.get('Y4_NO_INFER_CACHE') != '1'
                                                               and cfg.get('weight_param') is not None) else None
             z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32, x_amax=x_amax, w_prepared=wprep)
             if act != 'linear':
@@ -593,9 +633,18 @@ class ConvBNActFn(torch.autograd.Function):
             # conv mode 3: dy leaves the BatchNorm backward sweep already split into its two fp16 planes (DY_PLANES)
             planes = new_amax(dz.device, 8) if (f16 and DY_PLANES['dgrad'] and y.shape[1] % 32 == 0) else None
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
+            # column sums deposited by the sole consumer's dgrad -- valid only for the very tensor it produced, untouched
+            # (an accumulated / replaced gradient has another address or a bumped version counter)
+            pre = None
+            box = getattr(ctx, 'bn_box', None)
+            sums = box['slot'].pop('sums', None) if box is not None else None
+            if (sums is not None and planes is None and dz.data_ptr() == sums[2] and dz._version == sums[3]
+                    and tuple(dz.shape) == sums[4] and dz.stride() == sums[5]):
+                pre = (sums[0], sums[1])
+            BN_FOLD['folded' if pre is not None else 'swept'] += 1
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                                gp.grad if sink else None, bp.grad if sink else None,
-                                               out_amax=None if planes is not None else dy_amax, planes=planes)
+                                               out_amax=None if planes is not None else dy_amax, planes=planes, pre=pre)
             dy_planes = planes is not None
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
@@ -622,7 +671,13 @@ class ConvBNActFn(torch.autograd.Function):
                 raise Y4Error('gradient wrt the network input (stem, Cin=3) is not implemented')
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
-            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad, dy_planes=dy_planes)
+            src = getattr(ctx, 'bn_src', None)
+            if src is not None and not dy_planes:
+                dx, part, nparts = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad,
+                                                  bn_fold=src)
+                src['slot']['sums'] = (part, nparts, dx.data_ptr(), dx._version, tuple(dx.shape), dx.stride())
+            else:
+                dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad, dy_planes=dy_planes)
         elif skip_grad is not None:
             raise Y4Error('a parked skip gradient has no consumer (input of the 1x1 conv does not require grad)')
         dw = None
