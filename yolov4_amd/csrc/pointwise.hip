@@ -411,12 +411,16 @@ __global__ __launch_bounds__(PW_THREADS) void colsum_kernel(const float* __restr
     for (long long m = blockIdx.x; m < M; m += gridDim.x) s += x[m * ldx + c];
     part[(long long)blockIdx.x * C + c] = s;
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int R, int C,
+                                                              float* __restrict__ out) {
+    // 32 lanes per column: lane l adds partials l, l + 32, ... in index order, then a fixed xor tree (deterministic)
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
     double s = 0.0;
-    for (int r = 0; r < R; ++r) s += (double)part[(long long)r * C + c];
-    out[c] = (float)s;
+    if (c < C)
+        for (int r = l; r < R; r += 32) s += (double)part[(long long)r * C + c];
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 32);
+    if (c < C && l == 0) out[c] = (float)s;
 }
 
 __global__ void bn_fold_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -843,7 +847,7 @@ int y4_bias_grad_f32(const float* dy, int lddy, long long M, int C, float* dbias
     const int R = colsum_rows(M);
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)R, (C + 255) / 256), dim3(256), 0, st, dy, (long long)lddy, M, C, part);
     Y4_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, R, C, dbias);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, st, part, R, C, dbias);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
