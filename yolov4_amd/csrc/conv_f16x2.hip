@@ -1128,7 +1128,8 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
 // stays in LDS for the life of a persistent block and every wave streams its own 32 pixel rows from global memory
 // straight into the MFMA A-operand layout (lane = pixel, 8 consecutive channels = 32 contiguous bytes), splits them
 // in registers and never meets a barrier; the next tile's loads fly under this tile's MFMAs / stores.
-template <int KS, int NT, int NW = 4, bool APL = false>
+// RESB: the launch has a skip operand and a narrow tile (NT <= 2): its loads are batched ahead of the stores.
+template <int KS, int NT, int NW = 4, bool APL = false, bool RESB = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2(const ConvGeom g) {
     constexpr int NTHR = NW * 64, TROWS = NW * 32;
     constexpr int K = KS * 16;
@@ -1228,6 +1229,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + fr;
             const bool nok = n < g.N;
+            // narrow tiles (NT <= 2): the skip operand of the column is fetched as one batch before the stores, as in the
+            // gather kernel (at NT = 4 the 16 extra registers spill)
+            float rr[RESB ? 16 : 1];
+            if constexpr (RESB) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    rr[e] = (g.res && nok && m < g.M) ? g.res[(long long)m * g.ldr + n] : 0.f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float raw = acc0[j][e] * un + acc1[j][e] * un1;
@@ -1236,7 +1247,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
                 if (nok && m < g.M) {
                     float v = raw * sc[j] + sh[j];
                     v = y4_act(v, g.act);
-                    if (g.res) v += g.res[(long long)m * g.ldr + n];
+                    if constexpr (RESB) v += rr[e];
+                    else if (g.res) v += g.res[(long long)m * g.ldr + n];
                     g.dst[(long long)m * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
@@ -1300,14 +1312,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
     }
 }
 
-template <int KS, int NT, int NW, bool APL>
+template <int KS, int NT, int NW, bool APL, bool RESB>
 int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts);
 template <int KS, int NT, int NW = 4>
 int launch_stream1x1_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
-    if (g0.src_planes) return launch_stream1x1_f16x2_impl<KS, NT, NW, true>(g0, st, nparts);
-    return launch_stream1x1_f16x2_impl<KS, NT, NW, false>(g0, st, nparts);
+    if (g0.src_planes) return launch_stream1x1_f16x2_impl<KS, NT, NW, true, false>(g0, st, nparts);
+    if constexpr (NT <= 2) {
+        if (g0.res) return launch_stream1x1_f16x2_impl<KS, NT, NW, false, true>(g0, st, nparts);
+    }
+    return launch_stream1x1_f16x2_impl<KS, NT, NW, false, false>(g0, st, nparts);
 }
-template <int KS, int NT, int NW, bool APL>
+template <int KS, int NT, int NW, bool APL, bool RESB>
 int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts) {
     ConvGeom g = g0;
     g.mtiles = (g.M + NW * 32 - 1) / (NW * 32);
@@ -1316,7 +1331,7 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     size_t smem = (size_t)2 * NT * 32 * (KS * 32 + 16);
     const size_t red = (size_t)NW * NT * 32 * 2 * sizeof(float);
     if (smem < red) smem = red;
-    auto kern = conv1x1_stream_f16x2<KS, NT, NW, APL>;
+    auto kern = conv1x1_stream_f16x2<KS, NT, NW, APL, RESB>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1326,7 +1341,7 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     const int resident = NW == 8 ? 256 : 512;             // blocks per CU: 1 (8 waves) or 2
     const int grid = g.mtiles < resident ? g.mtiles : resident;
     if (nparts) *nparts = grid;
-    y4::note_kernel("conv1x1_stream_f16x2<%d, %d, %d, %s>", KS, NT, NW, APL ? "true" : "false");
+    y4::note_kernel("conv1x1_stream_f16x2<%d, %d, %d, %s, %s>", KS, NT, NW, APL ? "true" : "false", RESB ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
