@@ -93,6 +93,35 @@ def test_training_step_memory_is_flat(dev):
         _unwrap(ddp)
 
 
+def test_training_step_peak_memory_does_not_depend_on_optional_paths(dev):
+    """Plain attributes on an autograd ctx outlive the node's saved tensors: the BatchNorm-fold boxes once kept every pre-BN
+    tensor alive until the whole graph died (+27 GiB at bs = 64).  Peak memory of a step with the fold on must stay within
+    2 % of the default path's."""
+    from yolov4_amd import ops
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    m = _model(dev).train()
+    crit = YOLOLoss(CFG, 0.7, device=dev)
+    x = recipe.randn((4, 3, 256, 256), 5).to(dev)
+    labels = recipe.synth_labels(4, 256, 6).to(dev)
+    was_on = ops.BN_FOLD['on']
+    peaks = {}
+    try:
+        for on in (False, True):
+            ops.BN_FOLD['on'] = on
+            for _ in range(2):
+                m.zero_grad(set_to_none=True)
+                crit(m(x), {'padded_labels': labels}).backward()
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(dev)
+            m.zero_grad(set_to_none=True)
+            crit(m(x), {'padded_labels': labels}).backward()
+            torch.cuda.synchronize()
+            peaks[on] = torch.cuda.max_memory_allocated(dev)
+    finally:
+        ops.BN_FOLD['on'] = was_on
+    assert peaks[True] <= 1.02 * peaks[False], peaks
+
+
 # ------------------------------------------------------------------ stand-alone forms
 def test_bboxes_iou_golden_bit_exact(dev, golden):
     """yolo/model/yololoss.py:16-91 against the reference's own outputs (tests/golden/iou_nms.npz): bit-exact."""

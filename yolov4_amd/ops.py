@@ -585,7 +585,7 @@ class ConvBNActFn(torch.autograd.Function):
             z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
-            if io is not None and cfg.get('grad', True):
+            if io is not None and cfg.get('grad', True) and BN_FOLD['on']:
                 # producer box: what a sole 3x3 consumer needs to take this layer's BatchNorm-backward sums for it
                 ctx.bn_box = {'y': y, 'mean': mean, 'invstd': invstd, 'gamma': gamma.detach(), 'beta': beta.detach(),
                               'act': act, 'slot': {}}
@@ -641,6 +641,9 @@ class ConvBNActFn(torch.autograd.Function):
             if (sums is not None and planes is None and dz.data_ptr() == sums[2] and dz._version == sums[3]
                     and tuple(dz.shape) == sums[4] and dz.stride() == sums[5]):
                 pre = (sums[0], sums[1])
+            if box is not None:
+                box.clear()                   # plain ctx attributes outlive the node's saved tensors: drop the references
+                ctx.bn_box = None             # to y / mean / invstd now, not when the whole graph dies (+27 GiB otherwise)
             BN_FOLD['folded' if pre is not None else 'swept'] += 1
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                                gp.grad if sink else None, bp.grad if sink else None,
@@ -676,6 +679,7 @@ class ConvBNActFn(torch.autograd.Function):
                 dx, part, nparts = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad,
                                                   bn_fold=src)
                 src['slot']['sums'] = (part, nparts, dx.data_ptr(), dx._version, tuple(dx.shape), dx.stride())
+                ctx.bn_src = None
             else:
                 dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad, dy_planes=dy_planes)
         elif skip_grad is not None:
