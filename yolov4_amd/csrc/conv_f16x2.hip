@@ -1229,29 +1229,34 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + fr;
             const bool nok = n < g.N;
-            // narrow tiles (NT <= 2): the skip operand of the column is fetched as one batch before the stores, as in the
-            // gather kernel (at NT = 4 the 16 extra registers spill)
-            float rr[RESB ? 16 : 1];
-            if constexpr (RESB) {
+            // RESB: the skip operand is fetched in batches ahead of the stores (16 cells of a column at NT <= 2, 8 at NT = 4,
+            // where registers are short), as in the gather kernel: a load may not be moved across a store that might alias it
+            constexpr int RB = RESB ? (NT <= 2 ? 16 : 8) : 16;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = mbase + (e & 3) + 8 * (e >> 2);
-                    rr[e] = (g.res && nok && m < g.M) ? g.res[(long long)m * g.ldr + n] : 0.f;
+            for (int eb = 0; eb < 16; eb += RB) {
+                float rr[RESB ? RB : 1];
+                if constexpr (RESB) {
+#pragma unroll
+                    for (int e = 0; e < RB; ++e) {
+                        const int m = mbase + ((eb + e) & 3) + 8 * ((eb + e) >> 2);
+                        rr[e] = (g.res && nok && m < g.M) ? g.res[(long long)m * g.ldr + n] : 0.f;
+                    }
                 }
-            }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float raw = acc0[j][e] * un + acc1[j][e] * un1;
-                cs[j] += raw; css[j] += raw * raw;           // rows past M are exact zeros
-                const int m = mbase + (e & 3) + 8 * (e >> 2);
-                if (nok && m < g.M) {
-                    float v = raw * sc[j] + sh[j];
-                    v = y4_act(v, g.act);
-                    if constexpr (RESB) v += rr[e];
-                    else if (g.res) v += g.res[(long long)m * g.ldr + n];
-                    g.dst[(long long)m * g.ldd + n] = v;
-                    const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
-                    if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                for (int ee = 0; ee < RB; ++ee) {
+                    const int e = eb + ee;
+                    const float raw = acc0[j][e] * un + acc1[j][e] * un1;
+                    cs[j] += raw; css[j] += raw * raw;           // rows past M are exact zeros
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    if (nok && m < g.M) {
+                        float v = raw * sc[j] + sh[j];
+                        v = y4_act(v, g.act);
+                        if constexpr (RESB) v += rr[ee];
+                        else if (g.res) v += g.res[(long long)m * g.ldr + n];
+                        g.dst[(long long)m * g.ldd + n] = v;
+                        const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
+                        if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                    }
                 }
             }
         }
@@ -1317,7 +1322,7 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
 template <int KS, int NT, int NW = 4>
 int launch_stream1x1_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     if (g0.src_planes) return launch_stream1x1_f16x2_impl<KS, NT, NW, true, false>(g0, st, nparts);
-    if constexpr (NT <= 2) {
+    if constexpr (NT <= 2 || (KS == 8 && NT == 4)) {       // (the other NT = 4 forms spill 20-88 registers with the batch)
         if (g0.res) return launch_stream1x1_f16x2_impl<KS, NT, NW, false, true>(g0, st, nparts);
     }
     return launch_stream1x1_f16x2_impl<KS, NT, NW, false, false>(g0, st, nparts);
