@@ -118,6 +118,15 @@ constexpr int ROWB = 64;                                   // bytes per LDS row 
 //      its tile is then staged like the filter tile -- 16-B loads of each plane, ds_write_b128, no VALU.
 __device__ unsigned g_cu_arrivals[8 * 256];     // blocks seen per CU (stagger experiment)
 
+// LDS map of conv_gather_f16x2: [two staging buffers | re-used by the vector epilogue: 4 wave patches of
+// [WTM][WTN + 4] floats][row_m: BM ints]
+template <int BM, int BN, int WM, int WN, int MS>
+__host__ __device__ constexpr int gather_rowm_off() {       // byte offset of row_m[]: behind the stages AND the patches
+    constexpr int patches = (MS == 16 && BN / WN == 64) ? 4 * (BM / WM) * (BN / WN + 4) * 4 : 0;
+    constexpr int stages = 2 * 2 * (BM + BN) * ROWB;
+    return patches > stages ? patches : stages;
+}
+
 template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int MS, bool APL = false>
 __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     constexpr int BK = 32;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     static_assert(WM * WN == 4, "4 waves");
     typedef float accv __attribute__((ext_vector_type(ACCN)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    int* row_m = reinterpret_cast<int*>(smem_b + 2 * STAGE);
+    int* row_m = reinterpret_cast<int*>(smem_b + gather_rowm_off<BM, BN, WM, WN, MS>());
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -426,6 +435,68 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     const float un = f16x2_unscale(g.src_amax) * f16x2_unscale(g.wt_amax);
     const float un1 = un * (1.0f / 2048.0f);
     unsigned out_max = 0u;
+    // Vector form (16x16 shape, whole float4 columns, no BatchNorm-backward fold): in the MFMA layout a lane owns single
+    // floats of 4 rows, i.e. 64 scalar stores per lane, each wave instruction touching 4 rows x 64 B.  Instead every wave
+    // passes its WTM x WTN sub-tile through its own LDS patch ([row][WTN + 4] floats, no barrier: nobody else reads it) and
+    // writes float4 rows: 16 stores per lane, each instruction 4 rows x 256 contiguous bytes; the skip operand is read the
+    // same way.
+    bool vec = false;
+    if constexpr (MS == 16 && WTN == 64) {
+        vec = (g.N & 3) == 0 && (g.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 &&
+              (!g.res || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0)) &&
+              (!g.scale || (reinterpret_cast<uintptr_t>(g.scale) & 15) == 0) && (!g.shift || (reinterpret_cast<uintptr_t>(g.shift) & 15) == 0);
+        if constexpr (TRANSPOSED) vec = vec && !g.bn_part;
+    }
+    if (vec) {
+        constexpr int EP = WTN + 4;                        // patch row pitch in floats (272 B: 16-B aligned rows)
+        float* patch = reinterpret_cast<float*>(smem_b) + wave * (WTM * EP);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < ACCN; ++e) {
+                    const float raw = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                    acc0[i][j][e] = raw;                   // kept for the BN statistics below
+                    patch[(i * MS + 4 * fq + e) * EP + j * MS + fr] = raw;
+                }
+        // (wave-local: the LDS writes above are ordered before the reads below by the wave's own lgkmcnt wait)
+        const int c4 = (lane & 15) * 4;
+        const int nv = n0 + wn * WTN + c4;
+        const bool nok4 = nv < g.N;                         // N % 4 == 0: the four columns are valid together
+        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+        if (g.scale && nok4) sc4 = *reinterpret_cast<const f32x4*>(g.scale + nv);
+        if (g.shift && nok4) sh4 = *reinterpret_cast<const f32x4*>(g.shift + nv);
+#pragma unroll
+        for (int it = 0; it < WTM / 4; it += 4) {
+            int mrow[4];
+            f32x4 rr4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = (it + u) * 4 + (lane >> 4);
+                mrow[u] = row_m[wm * WTM + row];
+                rr4[u] = (g.res && nok4 && mrow[u] >= 0) ? *reinterpret_cast<const f32x4*>(g.res + (long long)mrow[u] * g.ldr + nv)
+                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = (it + u) * 4 + (lane >> 4);
+                f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * EP + c4);
+                if (nok4 && mrow[u] >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = v[q] * sc4[q] + sh4[q];
+                        t = y4_act(t, g.act);
+                        t += rr4[u][q];
+                        v[q] = t;
+                        const unsigned vb = __float_as_uint(t) & 0x7fffffffu;
+                        if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                    }
+                    *reinterpret_cast<f32x4*>(g.dst + (long long)mrow[u] * g.ldd + nv) = v;
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WTN + j * MS + fr;
@@ -491,7 +562,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     }
     float* const colsums = TRANSPOSED ? g.bn_part : g.stats;      // forward: BN statistics; dgrad: BN-backward sums
     if (colsums) {
-        float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the K loop ended with a barrier
+        __syncthreads();                                   // `red` lies inside wave 0's epilogue patch
+        float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float cs = 0.f, css = 0.f;
@@ -983,6 +1055,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
     const float un1 = un * (1.0f / 2048.0f);
     const long long mbase = (long long)b * HW + i0;
     unsigned out_max = 0u;
+    // vector form of the epilogue: see conv_gather_f16x2 (the staging buffers, 70 KB, hold the four wave patches)
+    bool vec = false;
+    if constexpr (MS == 16 && WTN == 64) {
+        vec = (g.N & 3) == 0 && (g.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 &&
+              (!g.res || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0)) &&
+              (!g.scale || (reinterpret_cast<uintptr_t>(g.scale) & 15) == 0) && (!g.shift || (reinterpret_cast<uintptr_t>(g.shift) & 15) == 0);
+        if constexpr (TRANSPOSED) vec = vec && !g.bn_part;
+    }
+    if (vec) {
+        constexpr int EP = WTN + 4;
+        static_assert(4 * WTM * EP * 4 <= 2 * HALO_ROWS * ROWB + 2 * 2 * BN * ROWB, "wave patches must fit the staging buffers");
+        float* patch = reinterpret_cast<float*>(smem_b) + wave * (WTM * EP);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < ACCN; ++e) {
+                    const int rl = wm * WTM + i * MS + 4 * fq + e;
+                    const float raw = rl < cnt ? acc0[i][j][e] * un + acc1[i][j][e] * un1 : 0.f;
+                    acc0[i][j][e] = raw;                   // kept for the BN statistics below (0 for rows past the image)
+                    patch[(i * MS + 4 * fq + e) * EP + j * MS + fr] = raw;
+                }
+        const int c4 = (lane & 15) * 4;
+        const int nv = n0 + wn * WTN + c4;
+        const bool nok4 = nv < g.N;
+        f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
+        if (g.scale && nok4) sc4 = *reinterpret_cast<const f32x4*>(g.scale + nv);
+        if (g.shift && nok4) sh4 = *reinterpret_cast<const f32x4*>(g.shift + nv);
+#pragma unroll
+        for (int it = 0; it < WTM / 4; it += 4) {
+            f32x4 rr4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rl = wm * WTM + (it + u) * 4 + (lane >> 4);
+                rr4[u] = (g.res && nok4 && rl < cnt) ? *reinterpret_cast<const f32x4*>(g.res + (mbase + rl) * g.ldr + nv)
+                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = (it + u) * 4 + (lane >> 4);
+                const int rl = wm * WTM + row;
+                f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * EP + c4);
+                if (nok4 && rl < cnt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float t = v[q] * sc4[q] + sh4[q];
+                        t = y4_act(t, g.act);
+                        t += rr4[u][q];
+                        v[q] = t;
+                        const unsigned vb = __float_as_uint(t) & 0x7fffffffu;
+                        if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                    }
+                    *reinterpret_cast<f32x4*>(g.dst + (mbase + rl) * g.ldd + nv) = v;
+                }
+            }
+        }
+    } else
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WTN + j * MS + fr;
@@ -1040,7 +1170,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
     }
     float* const colsums = TRANSPOSED ? g.bn_part : g.stats;      // forward: BN statistics; dgrad: BN-backward sums
     if (colsums) {
-        float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]; the step loop ended with a barrier
+        __syncthreads();                                   // `red` lies inside wave 0's epilogue patch
+        float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float cs = 0.f, css = 0.f;
@@ -1493,7 +1624,7 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
         if (!g.wt_planes) return Y4_ERR_WORKSPACE;
         g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
     }
-    size_t smem = 2ull * 2 * (BM + BN) * ROWB + BM * sizeof(int);
+    size_t smem = (size_t)gather_rowm_off<BM, BN, WM, WN, MS>() + BM * sizeof(int);
 #if Y4_STAMPS
     if (const char* e = getenv("Y4_EXTRA_LDS")) smem += (size_t)atoi(e);      // diagnostic: lower the occupancy
 #endif
