@@ -122,7 +122,7 @@ __device__ unsigned g_cu_arrivals[8 * 256];     // blocks seen per CU (stagger e
 // [WTM][WTN + 4] floats][row_m: BM ints]
 template <int BM, int BN, int WM, int WN, int MS>
 __host__ __device__ constexpr int gather_rowm_off() {       // byte offset of row_m[]: behind the stages AND the patches
-    constexpr int patches = (MS == 16 && BN / WN == 64) ? 4 * (BM / WM) * (BN / WN + 4) * 4 : 0;
+    constexpr int patches = (MS == 16 && (BN / WN == 64 || BN / WN == 32)) ? 4 * (BM / WM) * (BN / WN + 4) * 4 : 0;
     constexpr int stages = 2 * 2 * (BM + BN) * ROWB;
     return patches > stages ? patches : stages;
 }
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     // writes float4 rows: 16 stores per lane, each instruction 4 rows x 256 contiguous bytes; the skip operand is read the
     // same way.
     bool vec = false;
-    if constexpr (MS == 16 && WTN == 64) {
+    if constexpr (MS == 16 && (WTN == 64 || WTN == 32)) {
         vec = (g.N & 3) == 0 && (g.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 &&
               (!g.res || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0)) &&
               (!g.scale || (reinterpret_cast<uintptr_t>(g.scale) & 15) == 0) && (!g.shift || (reinterpret_cast<uintptr_t>(g.shift) & 15) == 0);
@@ -461,26 +461,27 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     patch[(i * MS + 4 * fq + e) * EP + j * MS + fr] = raw;
                 }
         // (wave-local: the LDS writes above are ordered before the reads below by the wave's own lgkmcnt wait)
-        const int c4 = (lane & 15) * 4;
+        constexpr int LPR = WTN / 4, RPI = 64 / LPR;       // lanes per patch row, rows per wave instruction
+        const int c4 = (lane % LPR) * 4;
         const int nv = n0 + wn * WTN + c4;
         const bool nok4 = nv < g.N;                         // N % 4 == 0: the four columns are valid together
         f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, sh4 = {0.f, 0.f, 0.f, 0.f};
         if (g.scale && nok4) sc4 = *reinterpret_cast<const f32x4*>(g.scale + nv);
         if (g.shift && nok4) sh4 = *reinterpret_cast<const f32x4*>(g.shift + nv);
 #pragma unroll
-        for (int it = 0; it < WTM / 4; it += 4) {
+        for (int it = 0; it < WTM / RPI; it += 4) {
             int mrow[4];
             f32x4 rr4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int row = (it + u) * 4 + (lane >> 4);
+                const int row = (it + u) * RPI + lane / LPR;
                 mrow[u] = row_m[wm * WTM + row];
                 rr4[u] = (g.res && nok4 && mrow[u] >= 0) ? *reinterpret_cast<const f32x4*>(g.res + (long long)mrow[u] * g.ldr + nv)
                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int row = (it + u) * 4 + (lane >> 4);
+                const int row = (it + u) * RPI + lane / LPR;
                 f32x4 v = *reinterpret_cast<const f32x4*>(patch + row * EP + c4);
                 if (nok4 && mrow[u] >= 0) {
 #pragma unroll
