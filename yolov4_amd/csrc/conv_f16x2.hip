@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             f32x4 v = ra[p];
-            if (TRANSPOSED) {
+            if (TRANSPOSED && g.Cs_valid != g.Cs) {        // pad channels of dy (255 -> 256) may hold anything
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
         for (int p = 0; p < PP; ++p) {
             if (a_lds[p] < 0) continue;
             f32x4 v = ra[p];
-            if (TRANSPOSED) {
+            if (TRANSPOSED && g.Cs_valid != g.Cs) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (cc * 32 + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
