@@ -655,16 +655,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
         y4_make_rsrc(reinterpret_cast<const char*>(g.dy) + dy_skip, (unsigned)(dy_left < 0xfffffff0ull ? dy_left : 0xfffffff0ull));
     const unsigned OOB = 0xffffffffu;
     const float s_dy = f16x2_scale(g.dy_amax), s_x = f16x2_scale(g.x_amax);
-    int pb_b[4], pb_h[4], pb_w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int pix = chunk0 * 32 + pg * 4 + i;
+    // raster position (image - b_first, row, column) of this thread's FIRST pixel of the chunk; its three neighbours are
+    // derived from it (one running state per thread instead of four)
+    int pb_b, pb_h, pb_w;
+    {
+        const int pix = chunk0 * 32 + pg * 4;
         const int pp = pix < g.M ? pix : (int)p_first;
         const int bb = pp / (g.Ho * g.Wo);
-        pb_b[i] = bb - b_first;
+        pb_b = bb - b_first;
         const int rem = pp - bb * (g.Ho * g.Wo);
-        pb_h[i] = rem / g.Wo;
-        pb_w[i] = rem - pb_h[i] * g.Wo;
+        pb_h = rem / g.Wo;
+        pb_w = rem - pb_h * g.Wo;
     }
     const unsigned a_off0 = an_ok ? (unsigned)(pg * 4) * (unsigned)g.lddy * 4u + (unsigned)(n0 + cg * 4) * 4u : OOB;
     const unsigned dy_pix_bytes = (unsigned)g.lddy * 4u;
@@ -705,14 +706,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
             const bool ok = an_ok && pbase + i < g.M;
             ra[i] = y4_buf_load4(dy_rsrc, ok ? a_off0 + (unsigned)i * dy_pix_bytes : OOB, (unsigned)ld_chunk * chunk_bytes);
         }
+        {
+            int qb = pb_b, qh = pb_h, qw = pb_w;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int hi = pb_h[i] * g.stride - g.pad + jr, wi = pb_w[i] * g.stride - g.pad + jq;
-            const bool ok = bj_ok && pbase + i < g.M && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-            const unsigned off = (unsigned)((pb_b[i] * g.H + hi) * g.W + wi) * x_pix_bytes + (unsigned)jc * 4u;
-            rb[i] = y4_buf_load4(x_rsrc, ok ? off : OOB, 0u);
-            pb_w[i] += 32;
-            while (pb_w[i] >= g.Wo) { pb_w[i] -= g.Wo; if (++pb_h[i] == g.Ho) { pb_h[i] = 0; ++pb_b[i]; } }
+            for (int i = 0; i < 4; ++i) {
+                const int hi = qh * g.stride - g.pad + jr, wi = qw * g.stride - g.pad + jq;
+                const bool ok = bj_ok && pbase + i < g.M && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                const unsigned off = (unsigned)((qb * g.H + hi) * g.W + wi) * x_pix_bytes + (unsigned)jc * 4u;
+                rb[i] = y4_buf_load4(x_rsrc, ok ? off : OOB, 0u);
+                if (++qw == g.Wo) { qw = 0; if (++qh == g.Ho) { qh = 0; ++qb; } }
+            }
+            pb_w += 32;
+            while (pb_w >= g.Wo) { pb_w -= g.Wo; if (++pb_h == g.Ho) { pb_h = 0; ++pb_b; } }
         }
         ++ld_chunk;
     };
