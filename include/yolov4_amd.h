@@ -68,8 +68,9 @@ int y4_device_count(void);
  *      out_amax) or, when NULL, from one extra pass over the operand inside the call. */
 int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
-/* Scratch arena for library temporaries whose size depends only on the layer (the pre-split filter
- * planes of mode 1: 6 B per filter element, <= 28.3 MB for YOLOv4).  Caller-owned device memory, used
+/* Scratch arena for library temporaries whose size depends only on the layer: a 1-KiB header (a ring of pre-zeroed
+ * words for the operand maxima the library takes itself) followed by the pre-split filter planes (6 B per filter
+ * element in mode 1, 4 B in mode 3: <= 28.3 MB for YOLOv4).  Caller-owned device memory, used
  * in stream order by every conv forward issued afterwards.  ONE arena per process: forward convs must be issued
  * from one stream of one device at a time (two streams or two devices in one process would race on the planes;
  * dgrad and wgrad take their plane workspace per call and have no such restriction);

@@ -1779,8 +1779,8 @@ int f16x2_transpose_split_filter(const float* w, unsigned short* planes, int Cou
     return Y4_OK;
 }
 
-int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st) {
-    if (hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st) != hipSuccess) return Y4_ERR_LAUNCH;
+int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st, bool prezeroed) {
+    if (!prezeroed && hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st) != hipSuccess) return Y4_ERR_LAUNCH;
     if (M <= 0 || C <= 0) return Y4_OK;
     // 16-B loads when every row starts on a 16-B boundary and a row's last vector stays inside its pitch
     if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ((C + 3) & ~3) <= ld) {

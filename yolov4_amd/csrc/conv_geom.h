@@ -67,7 +67,8 @@ int f16x2_wgrad(const WgradGeom& g, hipStream_t st);
 int f16x2_split_filter(const float* w, unsigned short* planes, long long n, const unsigned* amax, hipStream_t st);
 int f16x2_transpose_split_filter(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
                                  const unsigned* amax, hipStream_t st);
-int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st);   // zeroes the word first
+int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st,
+                bool prezeroed = false);     // zeroes the word first unless the caller hands in a zeroed one
 int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st);
 
 

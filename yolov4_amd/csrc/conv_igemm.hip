@@ -1749,7 +1749,21 @@ int y4_set_workspace(void* ptr, size_t bytes) {
 
 // scratch arena layout: 256 bytes of amax words (f16x2 mode: [0] filter, [1] gathered tensor when the caller gave none),
 // then the filter planes
-constexpr size_t SCRATCH_HDR = 256;
+constexpr size_t SCRATCH_HDR = 1024;
+// Words 64..191 of the scratch header: a ring of pre-zeroed cells for the operand maxima the library takes itself (filters
+// on every call, activations without a producer-side cell).  One 512-B memset refills the ring every 128 uses instead of
+// one 4-B memset per use; a cell is consumed by the kernels enqueued right behind its amax pass, so stream order makes
+// the reuse safe (same one-stream-at-a-time rule as the arena itself).
+constexpr int AMAX_RING = 128;
+unsigned* next_zero_cell(hipStream_t st) {
+    static int idx = 0;
+    static void* owner = nullptr;
+    if (!g_scratch || g_scratch_bytes < SCRATCH_HDR) return nullptr;
+    unsigned* ring = static_cast<unsigned*>(g_scratch) + 64;
+    if (owner != g_scratch) { owner = g_scratch; idx = 0; }             // a new arena starts with a refill
+    if (idx % AMAX_RING == 0 && hipMemsetAsync(ring, 0, AMAX_RING * sizeof(unsigned), st) != hipSuccess) return nullptr;
+    return ring + (idx++ % AMAX_RING);
+}
 
 static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
@@ -1794,16 +1808,20 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
         unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(g_scratch) + SCRATCH_HDR);
         g.wt_planes = planes;
         if (g_conv_mode == 3) {
-            int rc = y4::amax_launch(w, g.K, Cout, g.K, hdr, y4_stream(stream));
+            unsigned* wcell = next_zero_cell(y4_stream(stream));
+            if (!wcell) return Y4_ERR_LAUNCH;
+            int rc = y4::amax_launch(w, g.K, Cout, g.K, wcell, y4_stream(stream), true);
             if (rc != Y4_OK) return rc;
-            rc = y4::f16x2_split_filter(w, planes, nw, hdr, y4_stream(stream));
+            rc = y4::f16x2_split_filter(w, planes, nw, wcell, y4_stream(stream));
             if (rc != Y4_OK) return rc;
             if (!x_amax) {                                  // no producer-side maximum: one extra pass over the input
-                rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, hdr + 1, y4_stream(stream));
+                unsigned* xcell = next_zero_cell(y4_stream(stream));
+                if (!xcell) return Y4_ERR_LAUNCH;
+                rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, xcell, y4_stream(stream), true);
                 if (rc != Y4_OK) return rc;
-                x_amax = hdr + 1;
+                x_amax = xcell;
             }
-            g.src_amax = x_amax; g.wt_amax = hdr; g.dst_amax = y_amax;
+            g.src_amax = x_amax; g.wt_amax = wcell; g.dst_amax = y_amax;
             g.stamps = reinterpret_cast<unsigned long long*>(hdr + 16);      // scratch header words 64..127 (diagnostic builds)
             return y4::f16x2_gather(g, false, y4_stream(stream), nparts);
         }
@@ -1888,10 +1906,13 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     const long long total = (long long)Cin * k * k * Cout_pad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)total * 6);
+    unsigned* wamax = hdr;
     if (g_conv_mode == 3) {
-        int rc = y4::amax_launch(w, (long long)k * k * Cin, Cout, k * k * Cin, hdr, st);
+        unsigned* wcell = next_zero_cell(st);              // (no arena registered: the call's own header word + a memset)
+        wamax = wcell ? wcell : hdr;
+        int rc = y4::amax_launch(w, (long long)k * k * Cin, Cout, k * k * Cin, wamax, st, wcell != nullptr);
         if (rc != Y4_OK) return rc;
-        rc = y4::f16x2_transpose_split_filter(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad, hdr, st);
+        rc = y4::f16x2_transpose_split_filter(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad, wamax, st);
         if (rc != Y4_OK) return rc;
     } else if (g_conv_mode != 0)
         hipLaunchKernelGGL(transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w,
@@ -1922,7 +1943,7 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
             if (rc != Y4_OK) return rc;
             dy_amax = hdr + 1;
         }
-        g.src_amax = dy_amax; g.wt_amax = hdr;
+        g.src_amax = dy_amax; g.wt_amax = wamax;
         if (g_scratch && g_scratch_bytes >= SCRATCH_HDR) g.stamps = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(g_scratch) + 16);
         if (fold) {
             g.bn_y = fold->y; g.bn_ld = fold->ld; g.bn_mean = fold->mean; g.bn_invstd = fold->invstd;
