@@ -116,8 +116,6 @@ constexpr int ROWB = 64;                                   // bytes per LDS row 
 // TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
 // APL: the gathered tensor arrives pre-split (ConvGeom::src_planes: dy planes written by the BatchNorm backward sweep);
 //      its tile is then staged like the filter tile -- 16-B loads of each plane, ds_write_b128, no VALU.
-__device__ unsigned g_cu_arrivals[8 * 256];     // blocks seen per CU (stagger experiment)
-
 // LDS map of conv_gather_f16x2: [two staging buffers | re-used by the vector epilogue: 4 wave patches of
 // [WTM][WTN + 4] floats][row_m: BM ints]
 template <int BM, int BN, int WM, int WN, int MS>
@@ -377,19 +375,6 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     };
 
     const int KT = nr * nq * CC;
-    if (g.stagger > 0) {
-        // Two blocks share a CU (one wave of each per SIMD).  Launched together they run their phases (split, load
-        // issue, MFMA) in lockstep, each unit contended twice over and idle otherwise; the block in the odd wave
-        // slot starts half an iteration late so that one block's MFMAs cover the other's loads and splits.
-        const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | 4);        // HW_ID[15:0]: ... CU_ID[11:8] SH_ID[12] SE_ID[15:13]
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // XCC_ID[3:0]
-        if (tid == 0) row_m[0] = (int)atomicAdd(&g_cu_arrivals[(xcc & 7) * 256 + ((hw >> 8) & 255)], 1u);
-        __syncthreads();
-        const int arrival = row_m[0];
-        __syncthreads();
-        if (arrival & 1)
-            for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     load_tile();
     store_tile(0);
     if (KT > 1) load_tile();
@@ -1634,11 +1619,6 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
 #if Y4_STAMPS
     if (const char* e = getenv("Y4_EXTRA_LDS")) smem += (size_t)atoi(e);      // diagnostic: lower the occupancy
 #endif
-    {
-        static int stg = -1;
-        if (stg < 0) { const char* e = getenv("Y4_STAGGER"); stg = e ? atoi(e) : 0; }
-        g.stagger = stg;
-    }
     auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS, APL>;
     static bool attr_done = false;
     if (!attr_done) {

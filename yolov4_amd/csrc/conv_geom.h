@@ -42,7 +42,6 @@ struct ConvGeom {
     const float* bn_beta;
     float* bn_part;               // [tiles][2][N] partial sums (nullptr: no fold)
     int bn_ld, bn_act;
-    int stagger;                  // > 0: blocks in an odd wave slot start their K loop 64*stagger cycles late (see conv_f16x2.hip)
     unsigned long long* stamps;   // diagnostic builds only (Y4_STAMPS): cycle sums per loop segment
     int src_planes;               // f16x2: the gathered tensor is already split: per pixel [Cs hi halfs][Cs lo halfs] (4 Cs bytes)
 };
