@@ -68,16 +68,6 @@ int y4_device_count(void);
  *      out_amax) or, when NULL, from one extra pass over the operand inside the call. */
 int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
-/* Scratch arena for library temporaries whose size depends only on the layer: a 1-KiB header (a ring of pre-zeroed
- * words for the operand maxima the library takes itself) followed by the pre-split filter planes (6 B per filter
- * element in mode 1, 4 B in mode 3: <= 28.3 MB for YOLOv4).  Caller-owned device memory, used
- * in stream order by every conv forward issued afterwards.  ONE arena per process: forward convs must be issued
- * from one stream of one device at a time (two streams or two devices in one process would race on the planes;
- * dgrad and wgrad take their plane workspace per call and have no such restriction);
- * stays registered until replaced or reset with (NULL, 0).  Forward convs in mode 1 return
- * Y4_ERR_WORKSPACE when it is missing or too small. */
-int y4_set_workspace(void* ptr, size_t bytes);
-
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d inside ConvBNAct.forward, darknet/darknet.py:31-36,53-54
  * (k in {1,3}, stride in {1,2}, pad=(k-1)//2, dilation 1, groups 1).
@@ -89,17 +79,25 @@ int y4_set_workspace(void* ptr, size_t bytes);
  * ResBlock's skip into residual (darknet.py:76-80).  Implicit GEMM on
  * v_mfma_f32_32x32x2_f32 (exact fp32).  Requires Cin % 32 == 0, or Cin == 3 (stem,
  * yolov4.py:30: direct kernel, x given with arbitrary element strides).
+ * workspace: y4_conv2d_fwd_workspace() bytes of caller-owned device memory, 16-B aligned, private to the call in stream
+ * order (modes 1-3: the filter's maximum and its pre-split planes; 6 B per filter element + 4160 B).  The library keeps
+ * no state between calls: convs may be issued from any number of streams, devices and host threads at once.
  */
+size_t y4_conv2d_fwd_workspace(int Cin, int Cout, int k);
 int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                       int B, int H, int W, int Cin, int Cout, int k, int stride,
                       const float* scale, const float* shift, int act,
                       const float* residual, int ldr, const unsigned* x_amax /* mode 3, nullable */,
-                      unsigned* y_amax /* mode 3, nullable: max|finite y| folded in with atomicMax */, void* stream);
-/* Inference (filters constant between calls), conv mode 3: split a KRSC filter [Cout][K = k*k*Cin] once into the form
- * the forward kernels consume -- 64-B header (word 0: bit pattern of max|w|; word 1: scratch of the call) followed by the
- * fp16 hi/lo planes interleaved per 32-deep K tile, y4_conv2d_prepared_bytes(Cout, K) bytes in all -- and run the
- * forward conv from it: same arithmetic and results as y4_conv2d_fwd_f32, minus its per-call amax + split passes over the
- * filter.  The prepared buffer is caller-owned and must be refreshed when the filter changes.  (The reference has no
+                      unsigned* y_amax /* mode 3, nullable: max|finite y| folded in with atomicMax */,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* Inference, conv mode 3: keep a KRSC filter [Cout][K = k*k*Cin] in the form the forward kernels consume -- a 64-B header
+ * (word 0: bit pattern of max|w|; word 1: scratch of the conv call; words 2-5: 64-bit fingerprint, valid flag, ticket), 4 KiB of
+ * fingerprint partials, then the fp16 hi/lo planes interleaved per 32-deep K tile; y4_conv2d_prepared_bytes(Cout, K) bytes in
+ * all, whose first 64 bytes the caller ZEROES once after allocating.  y4_conv2d_prepare_filter_f32 is a REFRESH: it reads the
+ * filter once (maximum + exact positional checksum of its bit patterns) and re-splits it only if the bits differ from what
+ * the buffer holds -- decided on the device, so a stale buffer cannot be used whatever wrote the weights (optimizer kernels,
+ * `.data` writes, load_state_dict).  Call it before every y4_conv2d_fwd_prepared_f32: same arithmetic and results as
+ * y4_conv2d_fwd_f32 at one read pass instead of two reads + one write pass over the filter.  (The reference has no
  * counterpart: nn.Conv2d re-reads its weight every call.) */
 size_t y4_conv2d_prepared_bytes(int Cout, int K);
 int y4_conv2d_prepare_filter_f32(const float* w, int Cout, int K, void* prepared, size_t prepared_bytes, void* stream);
@@ -126,7 +124,8 @@ size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k
 int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                               int B, int H, int W, int Cin, int Cout, int k, int stride,
                               float* partials, size_t partial_bytes, long long* nparts_host,
-                              const unsigned* x_amax /* mode 3, nullable */, void* stream);
+                              const unsigned* x_amax /* mode 3, nullable */,
+                              void* workspace, size_t workspace_bytes /* as y4_conv2d_fwd_f32 */, void* stream);
 
 /* Stem conv (Cin = 3): x addressed as x[b*sxb + c*sxc + h*sxh + w*sxw] so both the NCHW
  * tensor the reference feeds (yolo/engine/build.py:60) and NHWC work without a copy.
@@ -148,21 +147,6 @@ int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, in
                         int dy_is_planes /* mode 3: dy was written by y4_bn_act_bwd_f32(f16_planes) -- per pixel [Cout hi
                            halfs][Cout lo halfs]; needs dy_amax = its word [5], lddy == Cout, Cout % 32 == 0 */,
                         const float* residual, int ldr, void* stream);
-
-/* y4_conv2d_dgrad_f32 for a 3x3 stride-1 conv (conv mode 3) whose input is the output of exactly one BatchNorm+act layer:
- * dx is that layer's dz, so the epilogue also takes the layer's BatchNorm-backward column sums per tile -- it reads the
- * layer's pre-BN tensor bn_y [B*H*W][bn_ld] (same pixels / channels as dx) and its mean / invstd / gamma / beta -- and
- * writes them to bn_partials ([*n_partials_host][2][Cin], y4_conv2d_dgrad_bnfold_partials() bytes) for
- * y4_bn_act_bwd_presummed_f32.  Autograd of darknet/darknet.py:53-56 as y4_conv2d_dgrad_f32 + y4_bn_act_bwd_f32, minus one
- * read sweep over dz and y. */
-size_t y4_conv2d_dgrad_bnfold_partials(int B, int H, int W, int Cin);
-int y4_conv2d_dgrad_bnfold_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
-                               int B, int H, int W, int Cin, int Cout, int k, int stride,
-                               void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
-                               const float* residual, int ldr,
-                               const float* bn_y, int bn_ld, const float* bn_mean, const float* bn_invstd,
-                               const float* bn_gamma, const float* bn_beta, int bn_act,
-                               float* bn_partials, size_t bn_partials_bytes, int* n_partials_host, void* stream);
 
 /* wgrad: dw[Cout][k][k][Cin] = sum_{b,ho,wo} dy (x) x -- autograd of nn.Conv2d wrt weight.
  * Split-K over pixels into fp32 slabs in `workspace`, reduced in a fixed order (deterministic). */
@@ -220,14 +204,6 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                          receives that bound and serves as dy_amax of y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 with
                          dy_is_planes = 1 */,
                       void* stream);
-/* BatchNorm backward whose two column sums (sum g, sum g*xhat with g = dz * act'(gamma*xhat+beta)) were already taken
- * per tile by the dgrad kernel that produced dz (y4_conv2d_dgrad_bnfold_f32): the reduce sweep over dz and y is skipped,
- * everything else is y4_bn_act_bwd_f32.  partials: [n_partials][2][C] fp32. */
-int y4_bn_act_bwd_presummed_f32(const float* dz, int lddz, const float* y, int ldy,
-                                const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                int act, float* dy, int lddy, float* dgamma, float* dbeta,
-                                long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                                const float* partials, int n_partials, void* stream);
 /* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249): two fixed-order stages, no atomics
  * (deterministic).  workspace: y4_bias_grad_workspace(M, C) bytes */
 size_t y4_bias_grad_workspace(long long M, int C);

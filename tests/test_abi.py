@@ -46,7 +46,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_workspace_queries_run_on_host():
     L = yolov4_amd.lib()
-    assert L.y4_conv2d_dgrad_workspace(128, 255, 3) == 128 * 9 * 256 * 6 + 64
+    assert L.y4_conv2d_dgrad_workspace(128, 255, 3) == 128 * 9 * 256 * 6 + 64 + 4096
+    assert L.y4_conv2d_fwd_workspace(128, 255, 3) == 64 + 4096 + 255 * 9 * 128 * 6
     assert L.y4_bn_workspace(1000, 64) >= 2 * 64 * 8
     assert L.y4_conv2d_wgrad_workspace(64, 76, 76, 128, 128, 3, 1) > 0
     assert L.y4_yolo_loss_workspace(4, 76, 3, 60, 80) > 4 * 3 * 76 * 76 * 4
@@ -55,11 +56,11 @@ def test_workspace_queries_run_on_host():
 
 def test_null_and_shape_errors_are_reported_before_any_launch():
     L = yolov4_amd.lib()
-    assert L.y4_conv2d_fwd_f32(None, 32, None, None, 32, 1, 8, 8, 32, 32, 3, 1, None, None, 0, None, 0, None, None, None) == 2
+    assert L.y4_conv2d_fwd_f32(None, 32, None, None, 32, 1, 8, 8, 32, 32, 3, 1, None, None, 0, None, 0, None, None, None, 0, None) == 2
     # Cin not a multiple of 32 -> shape error (pointers are fake but never dereferenced on the host)
     fake = 0x1000
-    assert L.y4_conv2d_fwd_f32(fake, 48, fake, fake, 32, 1, 8, 8, 48, 32, 3, 1, None, None, 0, None, 0, None, None, None) == 1
-    assert L.y4_conv2d_fwd_f32(fake, 32, fake, fake, 32, 1, 8, 8, 32, 32, 5, 1, None, None, 0, None, 0, None, None, None) == 1
+    assert L.y4_conv2d_fwd_f32(fake, 48, fake, fake, 32, 1, 8, 8, 48, 32, 3, 1, None, None, 0, None, 0, None, None, fake, 1 << 30, None) == 1
+    assert L.y4_conv2d_fwd_f32(fake, 32, fake, fake, 32, 1, 8, 8, 32, 32, 5, 1, None, None, 0, None, 0, None, None, fake, 1 << 30, None) == 1
 
 
 def test_state_dict_matches_reference_tree():

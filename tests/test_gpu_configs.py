@@ -1,0 +1,182 @@
+# -*- coding: utf-8 -*-
+"""BASELINE configs[3] and configs[4] -- the 8-GPU configurations -- as far as ONE MI355X can exercise them: the per-rank
+workload of each at its real size (main_amp.py:115-131 of the reference: amp + apex DDP on every rank).
+
+configs[4]: 608x608, 128 images per GPU, bf16 MFMA conv arithmetic, fp32 BatchNorm / loss / NMS.
+configs[3]: 608x608, 64 images per GPU, fp32-grade arithmetic, gradients exchanged through RCCL by BucketedDDP.
+
+The exchange between 8 ranks itself is NOT measured or checked here (one GPU): "unmeasured on > 1 GPU" stands."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import head as H
+from oracle import network as NW
+
+pytestmark = pytest.mark.gpu
+
+CFG = recipe.MODEL_CFG
+
+# Stated tolerances of the bf16 mixed-precision mode at its real size.  Operands carry 8 significant bits (2^-9 relative
+# rounding per element), accumulation is fp32: through 110 layers the logits move by ~1e-2 of their range.
+BF16_608 = {
+    'loss_rel': 2e-2,           # training loss, bs = 128, against the fp32-grade mode on the same batch
+    'score_mean': 1e-2,         # eval, one image, against the ORACLE (torch CPU fp32): |obj, cls| mean / max
+    'score_max': 0.25,
+    'xy_mean_px': 0.15,         # box centres, pixels
+    'wh_rel_mean': 2e-2,        # box sizes, relative
+}
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    import yolov4_amd
+    assert yolov4_amd.lib().y4_device_count() >= 1
+    return torch.device('cuda:0')
+
+
+def _model(dev, seed):
+    from yolov4_amd.yolo.model.yolov4 import YOLOv4
+    m = YOLOv4(CFG, device=dev)
+    sd = m.state_dict()
+    recipe.fill_state_dict_(sd, seed)
+    m.load_state_dict(sd)
+    return m.to(dev)
+
+
+def _step(m, crit, x, labels):
+    m.zero_grad(set_to_none=True)
+    loss = crit(m(x), {'padded_labels': labels})
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss
+
+
+def test_config4_bf16_per_rank_workload_at_608_bs128(dev):
+    """configs[4], one rank's share: 128 images at 608x608 through forward + loss + backward in bf16 conv arithmetic
+    (`set_conv_mode('bf16')`, the switch main_amp.py:53,115-119 makes with amp).  Size-independent properties at the full
+    size -- finite, the same order twice is bit-identical -- and the loss against the fp32-grade mode on the same batch;
+    then one 608x608 image in eval mode against the oracle, boxes and scores, at stated tolerances."""
+    import yolov4_amd
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    B, S = 128, 608
+    m = _model(dev, 77).train()
+    crit = YOLOLoss(CFG, 0.7, device=dev, mutate_outputs=False)
+    x = recipe.randn((B, 3, S, S), 401).to(dev)
+    labels = recipe.synth_labels(B, S, 402).to(dev)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    watch = ['head.yolo1.1.conv.weight', 'neck.pan.module2.4.conv.weight', 'backbone.stage3.part2.1.module_list.3.1.conv.weight',
+             'backbone.stem.conv.weight', 'backbone.stage5.transition.norm.weight']
+    old = yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode('bf16')
+        runs = []
+        for _ in range(2):
+            m.load_state_dict(sd0)
+            loss = _step(m, crit, x, labels)
+            grads = {k: p.grad.clone() for k, p in m.named_parameters() if k in watch}
+            assert len(grads) == len(watch)
+            runs.append((loss.clone(), grads))
+        peak = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+        (l_a, g_a), (l_b, g_b) = runs
+        assert bool(torch.isfinite(l_a)) and all(bool(torch.isfinite(g).all()) for g in g_a.values())
+        assert torch.equal(l_a, l_b), (float(l_a), float(l_b))
+        for k in watch:
+            assert torch.equal(g_a[k], g_b[k]), k
+        yolov4_amd.set_conv_mode('f16x2')
+        m.load_state_dict(sd0)
+        l_ref = _step(m, crit, x, labels)
+    finally:
+        yolov4_amd.set_conv_mode(old)
+    rel = abs(float(l_a) - float(l_ref)) / abs(float(l_ref))
+    print(f'configs[4] per-rank step: bf16 loss {float(l_a):.3f} vs fp32-grade {float(l_ref):.3f} (rel {rel:.2e}); '
+          f'peak HBM {peak:.1f} GiB at bs = {B}')
+    assert rel <= BF16_608['loss_rel'], rel
+    del x, labels, runs, g_a, g_b
+    m.zero_grad(set_to_none=True)
+    torch.cuda.empty_cache()
+
+    # ---- eval, one image, bf16 mode vs the oracle (same running statistics on both sides: calibrated once, fp32-grade)
+    m.load_state_dict(sd0)
+    recipe.calibrate_bn_(m, recipe.randn((8, 3, S, S), 403).to(dev))
+    net = NW.RefNet({k: v.cpu() for k, v in m.state_dict().items()}, CFG)
+    x1 = recipe.randn((1, 3, S, S), 404)
+    ref = net.forward_eval(x1)
+    m.eval()
+    try:
+        yolov4_amd.set_conv_mode('bf16')
+        with torch.no_grad():
+            out = m(x1.to(dev)).cpu().numpy()
+    finally:
+        yolov4_amd.set_conv_mode(old)
+    assert out.shape == ref.shape == (1, 22743, 85) and np.isfinite(out).all()
+    ds = np.abs(out[..., 4:] - ref[..., 4:])
+    dxy = np.abs(out[..., :2] - ref[..., :2])
+    dwh = np.abs(out[..., 2:4] - ref[..., 2:4]) / np.maximum(np.abs(ref[..., 2:4]), 1e-6)
+    print(f'configs[4] eval vs oracle (bf16): score diff mean {ds.mean():.3e} max {ds.max():.3e}; xy px mean {dxy.mean():.3e} '
+          f'max {dxy.max():.3e}; wh rel mean {dwh.mean():.3e} max {dwh.max():.3e}')
+    assert ds.mean() <= BF16_608['score_mean'] and ds.max() <= BF16_608['score_max']
+    assert dxy.mean() <= BF16_608['xy_mean_px'] and dwh.mean() <= BF16_608['wh_rel_mean']
+    # mixed precision really is in use: the fp32-grade mode sits two orders closer (test_model_matches_oracle_at_608)
+    assert ds.max() > 1e-5
+
+
+def test_config3_per_rank_step_through_rccl_bucketed_ddp_bs64(dev):
+    """configs[3], one rank's share: the bs = 64 608x608 step through BucketedDDP on a REAL process group (backend "nccl" =
+    RCCL, world_size 1 -- the most one GPU can host): parameters broadcast at wrap time, every bucket all-reduced with
+    ReduceOp.AVG from the gradient hooks.  With one rank the exchange is the identity, so the gradients must be
+    bit-equal to the same step without a process group."""
+    import torch.distributed as dist
+    from yolov4_amd.ddp import BucketedDDP
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    B, S = 64, 608
+    m = _model(dev, 99).train()
+    crit = YOLOLoss(CFG, 0.7, device=dev, mutate_outputs=False)
+    x = recipe.randn((B, 3, S, S), 411).to(dev)
+    labels = recipe.synth_labels(B, S, 412).to(dev)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    loss0 = _step(m, crit, x, labels)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.load_state_dict(sd0)
+    m.zero_grad(set_to_none=True)
+    assert not dist.is_initialized()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:29631', rank=0, world_size=1)
+    ddp = None
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **kw):
+        calls.append(t.numel() * t.element_size())
+        return real_all_reduce(t, *a, **kw)
+    dist.all_reduce = counting_all_reduce
+    try:
+        ddp = BucketedDDP(m)                                             # main_amp.py:131
+        assert ddp.use_dist and ddp.backend == 'nccl' and ddp.world == 1 and len(ddp.buckets) >= 8
+        for k, v in m.state_dict().items():                              # broadcast from rank 0 = unchanged
+            assert torch.equal(v, sd0[k]), k
+        loss1 = crit(ddp(x), {'padded_labels': labels})
+        loss1.backward()                                                 # collectives waited for by the autograd callback
+        torch.cuda.synchronize()
+        assert ddp._finished and all(b.pending == 0 and b.launched for b in ddp.buckets)
+        assert len(calls) == len(ddp.buckets) and sum(calls) >= 64885341 * 4, calls     # every bucket went through RCCL
+        assert torch.equal(loss1, loss0)
+        for k, p in m.named_parameters():
+            assert torch.equal(p.grad, ref[k]), k
+        msg = sum(b.flat.numel() for b in ddp.buckets) * 4 / 1e6
+        print(f'configs[3] per-rank step through RCCL (1 rank): {len(ddp.buckets)} buckets, {msg:.1f} MB exchanged, '
+              f'loss {float(loss1):.3f}; gradients bit-equal to the no-group run')
+    finally:
+        dist.all_reduce = real_all_reduce
+        if ddp is not None:
+            for h in ddp._hooks:
+                h.remove()
+            for p in m.parameters():
+                for a in ('_y4_grad_ready', '_y4_ddp', '_y4_grad_fresh'):
+                    if hasattr(p, a):
+                        delattr(p, a)
+        dist.destroy_process_group()

@@ -242,6 +242,104 @@ def test_conv_modes_accuracy_vs_fp64(dev):
     assert err['bf16x3'] <= 1.5 * err['f32'] and err['f16x2'] <= 1.5 * err['f32'], err
 
 
+# ------------------------------------------------------------------ f16x2: behaviour over the tensor's dynamic range
+# conv_f16x2.hip states: s x = hi + 2^-11 lo + e with |e| <= 2^-22 |s x| for |x| >= 2^-29 max|T| (floor 2^-50 max|T|),
+# products exact, lo*lo (2^-22) dropped, fp32 accumulation.  Per output cell that is an error of a few 2^-22 of
+# (|x| (*) |w|)(cell), the convolution of the absolute values -- a CELL-WISE bound, unlike `close()`, whose tolerance
+# scales with the tensor's largest value and would hide a lost operand next to an outlier.
+def _cellwise_bound_ok(y, ref64, absconv64, c=16.0, floor=0.0):
+    err = (y.double().cpu() - ref64).abs()
+    bound = c * 2.0 ** -22 * absconv64 + floor
+    bad = err > bound
+    assert not bool(bad.any()), (int(bad.sum()), float((err / (absconv64 + 1e-300)).max()))
+    return float((err / (absconv64 + 1e-300)).max())
+
+
+def _f16x2(fn):
+    import yolov4_amd
+    old = yolov4_amd.get_conv_mode()
+    yolov4_amd.set_conv_mode('f16x2')
+    try:
+        return fn()
+    finally:
+        yolov4_amd.set_conv_mode(old)
+
+
+def test_f16x2_one_huge_outlier_among_unit_activations(dev):
+    """(i) one 1e8 activation among O(1) values: the scale follows the outlier (2^-27 of it is still inside the
+    full-precision range 2^-29), so cells that never see the outlier keep fp32-grade accuracy."""
+    from yolov4_amd import ops
+    x = recipe.randn((2, 64, 20, 20), 51)
+    x[1, 17, 9, 11] = 1.0e8
+    w = recipe.randn((96, 64, 3, 3), 52, 1.0 / np.sqrt(576))
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    ab = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    worst = _f16x2(lambda: _cellwise_bound_ok(ops.conv_fwd_raw(cl(x, dev), cl(w, dev), 3, 1), ref, ab))
+    print('outlier: worst cell error / (|x| * |w|) =', worst)
+    # the same through the producer-side maximum (an upper bound is as good as the exact one)
+    xd = cl(x, dev)
+    cell = torch.tensor([np.float32(3.0e8).view(np.int32)], dtype=torch.int32, device=dev)
+    _f16x2(lambda: _cellwise_bound_ok(ops.conv_fwd_raw(xd, cl(w, dev), 3, 1, x_amax=cell), ref, ab))
+
+
+def test_f16x2_sparse_unit_gradient_over_a_tiny_background(dev):
+    """(ii) dy with 1 % O(1) cells and the rest 1e-9 * randn (what a detection loss produces: a few positives, a sea of
+    almost-zero objectness gradients), through dgrad and wgrad."""
+    from yolov4_amd import ops
+    B, Ci, Co, H = 2, 64, 96, 20
+    g = torch.Generator().manual_seed(53)
+    dy = 1e-9 * torch.randn((B, Co, H, H), generator=g)
+    hot = torch.rand((B, Co, H, H), generator=g) < 0.01
+    dy[hot] = torch.randn(int(hot.sum()), generator=g)
+    x = recipe.randn((B, Ci, H, H), 54)
+    w = recipe.randn((Co, Ci, 3, 3), 55, 1.0 / np.sqrt(576))
+    dx_ref = F.conv_transpose2d(dy.double(), w.double(), None, 1, 1)
+    dx_ab = F.conv_transpose2d(dy.double().abs(), w.double().abs(), None, 1, 1)
+    xp = F.pad(x.double(), (1, 1, 1, 1))
+    dw_ref = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64)
+    dw_ab = torch.zeros_like(dw_ref)
+    for r in range(3):
+        for q in range(3):
+            patch = xp[:, :, r:r + H, q:q + H]
+            dw_ref[:, :, r, q] = torch.einsum('bnhw,bchw->nc', dy.double(), patch)
+            dw_ab[:, :, r, q] = torch.einsum('bnhw,bchw->nc', dy.double().abs(), patch.abs())
+
+    def run():
+        dx = ops.conv_dgrad_raw(cl(dy, dev), cl(w, dev), (B, Ci, H, H), 3, 1)
+        a = _cellwise_bound_ok(dx, dx_ref, dx_ab)
+        dw = ops.conv_wgrad_raw(cl(x, dev), cl(dy, dev), (Co, Ci, 3, 3), 3, 1)
+        b = _cellwise_bound_ok(dw, dw_ref, dw_ab)
+        return a, b
+    print('sparse gradient: worst dgrad / wgrad cell error / (|a| * |b|) =', _f16x2(run))
+
+
+def test_f16x2_all_zero_and_extreme_magnitude_operands(dev):
+    """(iii) an all-zero operand (maximum 0 -> scale 1) gives exact zeros, no NaN; (iv) tensors whose maximum sits at the
+    ends of the fp32 range (the scale exponent is clamped, conv_f16x2.hip f16x2_scale_exp) stay finite and accurate."""
+    from yolov4_amd import ops
+    w = recipe.randn((64, 32, 3, 3), 56, 1.0 / np.sqrt(288))
+    x0 = torch.zeros(1, 32, 12, 12)
+
+    def zero():
+        y = ops.conv_fwd_raw(cl(x0, dev), cl(w, dev), 3, 1)
+        assert bool((y == 0).all())
+        y = ops.conv_fwd_raw(cl(recipe.randn((1, 32, 12, 12), 57), dev), cl(torch.zeros_like(w), dev), 3, 1)
+        assert bool((y == 0).all())
+    _f16x2(zero)
+    for expo in (-100, -60, 60, 100):
+        x = recipe.randn((1, 32, 12, 12), 58) * 2.0 ** expo
+        ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+        ab = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+        y = _f16x2(lambda: ops.conv_fwd_raw(cl(x, dev), cl(w, dev), 3, 1))
+        assert bool(torch.isfinite(y).all()), expo
+        _cellwise_bound_ok(y, ref, ab)
+    # subnormal maximum: no scale can lift it into fp16's range -- the documented behaviour is "taken unscaled", i.e. the
+    # operand rounds to zero; the result must be finite (zeros), never NaN
+    xs = recipe.randn((1, 32, 12, 12), 59) * 2.0 ** -140
+    y = _f16x2(lambda: ops.conv_fwd_raw(cl(xs, dev), cl(w, dev), 3, 1))
+    assert bool(torch.isfinite(y).all())
+
+
 # ------------------------------------------------------------------ ConvBNAct / blocks against the reference's goldens
 def _load_cba(g, name, dev):
     from yolov4_amd.darknet.darknet import ConvBNAct

@@ -29,8 +29,8 @@ PROTOTYPES = {
     'y4_device_count': (I, []),
     'y4_set_conv_mode': (I, [I]),
     'y4_get_conv_mode': (I, []),
-    'y4_set_workspace': (I, [P, Z]),
-    'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P, P]),
+    'y4_conv2d_fwd_workspace': (Z, [I, I, I]),
+    'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P, P, Z, P]),
     'y4_amax_f32': (I, [P, I, L, I, P, P]),
     'y4_conv2d_prepared_bytes': (Z, [I, I]),
     'y4_conv2d_prepare_filter_f32': (I, [P, I, I, P, Z, P]),
@@ -38,7 +38,7 @@ PROTOTYPES = {
     'y4_amax_merge_u32': (I, [P, P, P]),
     'y4_last_conv_kernel': (I, [ctypes.c_char_p, I]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
-    'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P]),
+    'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P, Z, P]),
     'y4_conv2d_stem_fwd_f32': (I, [P, L, L, L, L, P, P, I, I, I, I, I, P, P, I, P, P]),
     'y4_conv2d_dgrad_workspace': (Z, [I, I, I]),
     'y4_conv2d_dgrad_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, I, P, I, P]),
@@ -52,10 +52,6 @@ PROTOTYPES = {
     'y4_bn_stats_f32': (I, [P, I, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, P]),
     'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, P]),
-    'y4_bn_act_bwd_presummed_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, I, P]),
-    'y4_conv2d_dgrad_bnfold_partials': (Z, [I, I, I, I]),
-    'y4_conv2d_dgrad_bnfold_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, I,
-                                       P, I, P, P, P, P, I, P, Z, ctypes.POINTER(ctypes.c_int), P]),
     'y4_bias_grad_workspace': (Z, [L, I]),
     'y4_bias_grad_f32': (I, [P, I, L, I, P, P, Z, P]),
     'y4_bn_fold_f32': (I, [P, P, P, P, F, P, P, I, P]),

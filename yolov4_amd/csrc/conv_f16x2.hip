@@ -21,13 +21,6 @@
 #include <cstdlib>
 #include "conv_geom.h"
 
-#ifndef Y4_KNOCK
-#define Y4_KNOCK 0      // diagnostic builds only: 1 = no global loads in the K loop, 2 = no operand split, 3 = no MFMA
-#endif
-#ifndef Y4_STAMPS
-#define Y4_STAMPS 0
-#endif
-
 namespace {
 
 using y4::ConvGeom;
@@ -256,16 +249,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                 rap[p][1] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u + a_lo), 0);
             }
         } else {
-#if Y4_KNOCK != 4
 #pragma unroll
             for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
-#endif
         }
         const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 4u);
-#if Y4_KNOCK != 5
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)koff, 0);
-#endif
         if (++cc == CC) { cc = 0; q += tstep; if (q >= g.k) { q = q0; r += tstep; } tap_setup(); }
     };
     int st_cc = 0;
@@ -289,12 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     if (st_cc * BK + kc * 4 + e >= g.Cs_valid) v[e] = 0.f;
             }
             u32x2 hi, lo;
-#if Y4_KNOCK == 2
-            hi[0] = __builtin_bit_cast(unsigned, v[0]); hi[1] = __builtin_bit_cast(unsigned, v[1]);
-            lo[0] = __builtin_bit_cast(unsigned, v[2]); lo[1] = __builtin_bit_cast(unsigned, v[3]);
-#else
             split2x4(v, sa, hi, lo);
-#endif
             *reinterpret_cast<u32x2*>(as + a_lds[p]) = hi;
             *reinterpret_cast<u32x2*>(as + BM * ROWB + a_lds[p]) = lo;
         }
@@ -362,13 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     fa[pl] = *reinterpret_cast<const f16x8*>(base + pl * BM * ROWB + a_row + i * 16 * ROWB + co);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-#if Y4_KNOCK == 3
-                    asm volatile("" :: "v"(fa[0]), "v"(fa[1]), "v"(fb[j][0]), "v"(fb[j][1]));
-#else
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], fb[j][0], acc1[i][j], 0, 0, 0);
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][1], acc1[i][j], 0, 0, 0);
                     acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], fb[j][0], acc0[i][j], 0, 0, 0);
-#endif
                 }
             }
         }
@@ -379,41 +359,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     store_tile(0);
     if (KT > 1) load_tile();
     __syncthreads();
-#if Y4_STAMPS
-    // diagnostic build only (never shipped): where one K-tile iteration of a wave spends its cycles
-    unsigned long long t_store = 0, t_load = 0, t_comp = 0, t_bar = 0;
-#define Y4_T(x) { __builtin_amdgcn_sched_barrier(0); x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
-    for (int kt = 0; kt < KT; ++kt) {
-        unsigned long long a0, a1, a2, a3, a4;
-        Y4_T(a0);
-        if (kt + 1 < KT) store_tile((kt + 1) & 1);
-        Y4_T(a1);
-#if Y4_KNOCK != 1
-        if (kt + 2 < KT) load_tile();
-#endif
-#if Y4_KNOCK == 6
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // exposes the raw load latency in the 'load' segment
-#endif
-        Y4_T(a2);
-        compute(kt & 1);
-        asm volatile("s_nop 0" ::: "memory");
-        Y4_T(a3);
-        __syncthreads();
-        Y4_T(a4);
-        t_store += a1 - a0; t_load += a2 - a1; t_comp += a3 - a2; t_bar += a4 - a3;
-    }
-    if (lane == 0 && g.stamps) {
-        atomicAdd(g.stamps + 0, t_store); atomicAdd(g.stamps + 1, t_load); atomicAdd(g.stamps + 2, t_comp);
-        atomicAdd(g.stamps + 3, t_bar); atomicAdd(g.stamps + 4, (unsigned long long)KT);
-    }
-#else
     for (int kt = 0; kt < KT; ++kt) {
         if (kt + 1 < KT) store_tile((kt + 1) & 1);         // split + write the prefetched tile into the other stage
         if (kt + 2 < KT) load_tile();                      // its successor's loads fly under this tile's MFMAs
         compute(kt & 1);
         __syncthreads();
     }
-#endif
 
     // ---- epilogue: c = (acc0 + 2^-11 acc1) / (s_A s_B); element (row, col) of a tile:
     //   32x32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5);   16x16: col = lane & 15, row = 4 (lane >> 4) + e
@@ -430,8 +381,15 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         vec = (g.N & 3) == 0 && (g.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 &&
               (!g.res || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0)) &&
               (!g.scale || (reinterpret_cast<uintptr_t>(g.scale) & 15) == 0) && (!g.shift || (reinterpret_cast<uintptr_t>(g.shift) & 15) == 0);
-        if constexpr (TRANSPOSED) vec = vec && !g.bn_part;
     }
+    // both accumulators are combined once, ahead of the branch: acc1 is dead in either epilogue form (with it alive
+    // across the branch the 128x128 forward instance spilled 12 registers)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) acc0[i][j][e] = acc0[i][j][e] * un + acc1[i][j][e] * un1;   // also the BN statistics' input
     if (vec) {
         constexpr int EP = WTN + 4;                        // patch row pitch in floats (272 B: 16-B aligned rows)
         float* patch = reinterpret_cast<float*>(smem_b) + wave * (WTM * EP);
@@ -440,11 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < ACCN; ++e) {
-                    const float raw = acc0[i][j][e] * un + acc1[i][j][e] * un1;
-                    acc0[i][j][e] = raw;                   // kept for the BN statistics below
-                    patch[(i * MS + 4 * fq + e) * EP + j * MS + fr] = raw;
-                }
+                for (int e = 0; e < ACCN; ++e) patch[(i * MS + 4 * fq + e) * EP + j * MS + fr] = acc0[i][j][e];
         // (wave-local: the LDS writes above are ordered before the reads below by the wave's own lgkmcnt wait)
         constexpr int LPR = WTN / 4, RPI = 64 / LPR;       // lanes per patch row, rows per wave instruction
         const int c4 = (lane % LPR) * 4;
@@ -489,10 +443,6 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         const bool nok = n < g.N;
         const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
         const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
-        float bn_mu = 0.f, bn_is = 0.f, bn_ga = 0.f, bn_be = 0.f;
-        if constexpr (TRANSPOSED) {
-            if (g.bn_part && nok) { bn_mu = g.bn_mean[n]; bn_is = g.bn_invstd[n]; bn_ga = g.bn_gamma[n]; bn_be = g.bn_beta[n]; }
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             // the skip / fan-in operand of this tile column is fetched as one batch BEFORE the stores (the compiler may
@@ -505,18 +455,10 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                 mm[e] = row_m[wm * WTM + i * MS + rl];
                 rr[e] = (g.res && nok && mm[e] >= 0) ? g.res[(long long)mm[e] * g.ldr + n] : 0.f;
             }
-            float yy[ACCN];                                // BN-backward fold: the producer's pre-BN values of these cells
-            if constexpr (TRANSPOSED) {
-#pragma unroll
-                for (int e = 0; e < ACCN; ++e)
-                    yy[e] = (g.bn_part && nok && mm[e] >= 0) ? g.bn_y[(long long)mm[e] * g.bn_ld + n] : 0.f;
-            }
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
-                const float raw = acc0[i][j][e] * un + acc1[i][j][e] * un1;
-                acc0[i][j][e] = raw;                       // kept for the BN statistics below
+                const float raw = acc0[i][j][e];
                 const int m = mm[e];
-                float gg = 0.f, gx = 0.f;
                 if (nok && m >= 0) {
                     float v = raw * sc + sh;
                     v = y4_act(v, g.act);
@@ -524,16 +466,6 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                     g.dst[(long long)m * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
-                    if constexpr (TRANSPOSED) {
-                        if (g.bn_part) {
-                            const float xh = (yy[e] - bn_mu) * bn_is;
-                            gg = v * y4_act_grad(bn_ga * xh + bn_be, g.bn_act);
-                            gx = gg * xh;
-                        }
-                    }
-                }
-                if constexpr (TRANSPOSED) {
-                    if (g.bn_part) { acc0[i][j][e] = gg; acc1[i][j][e] = gx; }
                 }
             }
         }
@@ -546,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         }
         if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
     }
-    float* const colsums = TRANSPOSED ? g.bn_part : g.stats;      // forward: BN statistics; dgrad: BN-backward sums
+    float* const colsums = TRANSPOSED ? nullptr : g.stats;       // forward only: BatchNorm statistics
     if (colsums) {
         __syncthreads();                                   // `red` lies inside wave 0's epilogue patch
         float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]
@@ -559,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
                 for (int e = 0; e < ACCN; ++e) {
                     const float v = acc0[i][j][e];
                     cs += v;
-                    css += TRANSPOSED ? acc1[i][j][e] : v * v;
+                    css += v * v;
                 }
             if constexpr (MS == 16) {
                 cs += __shfl_xor(cs, 16, 64);
@@ -1052,8 +984,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
         vec = (g.N & 3) == 0 && (g.ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(g.dst) & 15) == 0 &&
               (!g.res || ((g.ldr & 3) == 0 && (reinterpret_cast<uintptr_t>(g.res) & 15) == 0)) &&
               (!g.scale || (reinterpret_cast<uintptr_t>(g.scale) & 15) == 0) && (!g.shift || (reinterpret_cast<uintptr_t>(g.shift) & 15) == 0);
-        if constexpr (TRANSPOSED) vec = vec && !g.bn_part;
     }
+    // combined once ahead of the branch (see the gather kernel); rows past the image end become exact zeros (BN statistics)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < ACCN; ++e) {
+                const int rl = wm * WTM + i * MS + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
+                acc0[i][j][e] = rl < cnt ? acc0[i][j][e] * un + acc1[i][j][e] * un1 : 0.f;
+            }
     if (vec) {
         constexpr int EP = WTN + 4;
         static_assert(4 * WTM * EP * 4 <= 2 * HALO_ROWS * ROWB + 2 * 2 * BN * ROWB, "wave patches must fit the staging buffers");
@@ -1063,12 +1004,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < ACCN; ++e) {
-                    const int rl = wm * WTM + i * MS + 4 * fq + e;
-                    const float raw = rl < cnt ? acc0[i][j][e] * un + acc1[i][j][e] * un1 : 0.f;
-                    acc0[i][j][e] = raw;                   // kept for the BN statistics below (0 for rows past the image)
-                    patch[(i * MS + 4 * fq + e) * EP + j * MS + fr] = raw;
-                }
+                for (int e = 0; e < ACCN; ++e) patch[(i * MS + 4 * fq + e) * EP + j * MS + fr] = acc0[i][j][e];
         const int c4 = (lane & 15) * 4;
         const int nv = n0 + wn * WTN + c4;
         const bool nok4 = nv < g.N;
@@ -1110,26 +1046,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
         const bool nok = n < g.N;
         const float sc = (g.scale && nok) ? g.scale[n] : 1.0f;
         const float sh = (g.shift && nok) ? g.shift[n] : 0.0f;
-        float bn_mu = 0.f, bn_is = 0.f, bn_ga = 0.f, bn_be = 0.f;
-        if constexpr (TRANSPOSED) {
-            if (g.bn_part && nok) { bn_mu = g.bn_mean[n]; bn_is = g.bn_invstd[n]; bn_ga = g.bn_gamma[n]; bn_be = g.bn_beta[n]; }
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            float rr[ACCN], yy[ACCN];
+            float rr[ACCN];
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
                 const int rl = wm * WTM + i * MS + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
                 rr[e] = (g.res && nok && rl < cnt) ? g.res[(mbase + rl) * g.ldr + n] : 0.f;
-                if constexpr (TRANSPOSED) yy[e] = (g.bn_part && nok && rl < cnt) ? g.bn_y[(mbase + rl) * g.bn_ld + n] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < ACCN; ++e) {
                 const int rl = wm * WTM + i * MS + (MS == 32 ? (e & 3) + 8 * (e >> 2) + 4 * fq : 4 * fq + e);
                 const bool rok = rl < cnt;
-                const float raw = rok ? acc0[i][j][e] * un + acc1[i][j][e] * un1 : 0.f;
-                acc0[i][j][e] = raw;                       // kept for the BN statistics below (0 for rows past the image)
-                float gg = 0.f, gx = 0.f;
+                const float raw = acc0[i][j][e];
                 if (nok && rok) {
                     float v = raw * sc + sh;
                     v = y4_act(v, g.act);
@@ -1137,16 +1066,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
                     g.dst[(mbase + rl) * g.ldd + n] = v;
                     const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
                     if (vb < 0x7f800000u && vb > out_max) out_max = vb;
-                    if constexpr (TRANSPOSED) {
-                        if (g.bn_part) {                   // BN-backward fold (see the gather kernel)
-                            const float xh = (yy[e] - bn_mu) * bn_is;
-                            gg = v * y4_act_grad(bn_ga * xh + bn_be, g.bn_act);
-                            gx = gg * xh;
-                        }
-                    }
-                }
-                if constexpr (TRANSPOSED) {
-                    if (g.bn_part) { acc0[i][j][e] = gg; acc1[i][j][e] = gx; }
                 }
             }
         }
@@ -1159,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
         }
         if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
     }
-    float* const colsums = TRANSPOSED ? g.bn_part : g.stats;      // forward: BN statistics; dgrad: BN-backward sums
+    float* const colsums = TRANSPOSED ? nullptr : g.stats;       // forward only: BatchNorm statistics
     if (colsums) {
         __syncthreads();                                   // `red` lies inside wave 0's epilogue patch
         float* red = reinterpret_cast<float*>(smem_b);     // [WM][BN][2]
@@ -1172,7 +1091,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
                 for (int e = 0; e < ACCN; ++e) {
                     const float v = acc0[i][j][e];
                     cs += v;
-                    css += TRANSPOSED ? acc1[i][j][e] : v * v;
+                    css += v * v;
                 }
             if constexpr (MS == 16) {
                 cs += __shfl_xor(cs, 16, 64);
@@ -1250,8 +1169,10 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
 // stays in LDS for the life of a persistent block and every wave streams its own 32 pixel rows from global memory
 // straight into the MFMA A-operand layout (lane = pixel, 8 consecutive channels = 32 contiguous bytes), splits them
 // in registers and never meets a barrier; the next tile's loads fly under this tile's MFMAs / stores.
-// RESB: the launch has a skip operand and a narrow tile (NT <= 2): its loads are batched ahead of the stores.
-template <int KS, int NT, int NW = 4, bool APL = false, bool RESB = false>
+// RESB: the launch has a skip operand: its loads are batched ahead of the stores.
+// PLAIN: no scale / shift / activation / BatchNorm statistics (a dgrad launch): 16 fewer live registers, which the
+//        K = N = 128 form with a skip operand needs to stay out of scratch.
+template <int KS, int NT, int NW = 4, bool APL = false, bool RESB = false, bool PLAIN = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2(const ConvGeom g) {
     constexpr int NTHR = NW * 64, TROWS = NW * 32;
     constexpr int K = KS * 16;
@@ -1301,14 +1222,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
             ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 64u + 16u);
         }
     };
-    float cs[NT], css[NT];
-    float sc[NT], sh[NT];
+    float cs[PLAIN ? 1 : NT], css[PLAIN ? 1 : NT];
+    float sc[PLAIN ? 1 : NT], sh[PLAIN ? 1 : NT];
+    if constexpr (!PLAIN) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        cs[j] = 0.f; css[j] = 0.f;
-        const int n = j * 32 + fr;
-        sc[j] = (g.scale && n < g.N) ? g.scale[n] : 1.0f;
-        sh[j] = (g.shift && n < g.N) ? g.shift[n] : 0.0f;
+        for (int j = 0; j < NT; ++j) {
+            cs[j] = 0.f; css[j] = 0.f;
+            const int n = j * 32 + fr;
+            sc[j] = (g.scale && n < g.N) ? g.scale[n] : 1.0f;
+            sh[j] = (g.shift && n < g.N) ? g.shift[n] : 0.0f;
+        }
     }
     const unsigned char* b_frag = smem_b + fr * PITCH + fh * 16;
     f32x16 acc0[NT], acc1[NT];
@@ -1368,11 +1291,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
                 for (int ee = 0; ee < RB; ++ee) {
                     const int e = eb + ee;
                     const float raw = acc0[j][e] * un + acc1[j][e] * un1;
-                    cs[j] += raw; css[j] += raw * raw;           // rows past M are exact zeros
+                    if constexpr (!PLAIN) { cs[j] += raw; css[j] += raw * raw; }      // rows past M are exact zeros
                     const int m = mbase + (e & 3) + 8 * (e >> 2);
                     if (nok && m < g.M) {
-                        float v = raw * sc[j] + sh[j];
-                        v = y4_act(v, g.act);
+                        float v = raw;
+                        if constexpr (!PLAIN) {
+                            v = raw * sc[j] + sh[j];
+                            v = y4_act(v, g.act);
+                        }
                         if constexpr (RESB) v += rr[ee];
                         else if (g.res) v += g.res[(long long)m * g.ldr + n];
                         g.dst[(long long)m * g.ldd + n] = v;
@@ -1416,7 +1342,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         }
         if (lane == 0 && out_max > __hip_atomic_load(g.dst_amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(g.dst_amax, out_max);
     }
-    if (g.stats) {                                        // one partial row per block: [gridDim][2][N]
+    if (!PLAIN && g.stats) {                              // one partial row per block: [gridDim][2][N]
         __syncthreads();                                  // every wave is done with the filter planes
         float* red = reinterpret_cast<float*>(smem_b);    // [NW][N32][2]
 #pragma unroll
@@ -1439,17 +1365,20 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
     }
 }
 
-template <int KS, int NT, int NW, bool APL, bool RESB>
+template <int KS, int NT, int NW, bool APL, bool RESB, bool PLAIN = false>
 int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts);
 template <int KS, int NT, int NW = 4>
 int launch_stream1x1_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     if (g0.src_planes) return launch_stream1x1_f16x2_impl<KS, NT, NW, true, false>(g0, st, nparts);
-    if constexpr (NT <= 2 || (KS == 8 && NT == 4)) {       // (the other NT = 4 forms spill 20-88 registers with the batch)
+    if constexpr (KS == 8 && NT == 4) {                    // K = N = 128 with a skip operand: in registers only as PLAIN
+        if (g0.res && !g0.scale && !g0.shift && !g0.stats && g0.act == Y4_ACT_LINEAR)
+            return launch_stream1x1_f16x2_impl<KS, NT, NW, false, true, true>(g0, st, nparts);
+    } else if constexpr (NT <= 2) {                        // (the other NT = 4 forms spill 20-88 registers with the batch)
         if (g0.res) return launch_stream1x1_f16x2_impl<KS, NT, NW, false, true>(g0, st, nparts);
     }
     return launch_stream1x1_f16x2_impl<KS, NT, NW, false, false>(g0, st, nparts);
 }
-template <int KS, int NT, int NW, bool APL, bool RESB>
+template <int KS, int NT, int NW, bool APL, bool RESB, bool PLAIN>
 int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts) {
     ConvGeom g = g0;
     g.mtiles = (g.M + NW * 32 - 1) / (NW * 32);
@@ -1458,7 +1387,7 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     size_t smem = (size_t)2 * NT * 32 * (KS * 32 + 16);
     const size_t red = (size_t)NW * NT * 32 * 2 * sizeof(float);
     if (smem < red) smem = red;
-    auto kern = conv1x1_stream_f16x2<KS, NT, NW, APL, RESB>;
+    auto kern = conv1x1_stream_f16x2<KS, NT, NW, APL, RESB, PLAIN>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1468,7 +1397,8 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     const int resident = NW == 8 ? 256 : 512;             // blocks per CU: 1 (8 waves) or 2
     const int grid = g.mtiles < resident ? g.mtiles : resident;
     if (nparts) *nparts = grid;
-    y4::note_kernel("conv1x1_stream_f16x2<%d, %d, %d, %s, %s>", KS, NT, NW, APL ? "true" : "false", RESB ? "true" : "false");
+    y4::note_kernel("conv1x1_stream_f16x2<%d, %d, %d, %s, %s, %s>", KS, NT, NW, APL ? "true" : "false", RESB ? "true" : "false",
+                    PLAIN ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1501,39 +1431,6 @@ int dispatch_stream1x1_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
 }
 
 // ==================================================================================== filter planes, amax
-__global__ __launch_bounds__(256) void f16x2_split_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
-                                                                 long long n, const unsigned* __restrict__ amax) {
-    const float s = f16x2_scale(amax);
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        unsigned short hi, lo;
-        split2(w[i], s, hi, lo);
-        const long long o = (i >> 5) * 64 + (i & 31);          // per 32-deep K-tile: [32 hi][32 lo] (rows are whole K-tiles)
-        planes[o] = hi;
-        planes[o + 32] = lo;
-    }
-}
-
-// [Cout][k][k][Cin] fp32 -> 2 fp16 planes of [Cin][k][k][Cout_pad] (dgrad filter)
-__global__ __launch_bounds__(256) void f16x2_transpose_split_filter_kernel(const float* __restrict__ w,
-                                                                           unsigned short* __restrict__ planes, int Cout, int Cin,
-                                                                           int kk, int Cout_pad, const unsigned* __restrict__ amax) {
-    const float s = f16x2_scale(amax);
-    const long long total = (long long)Cin * kk * Cout_pad;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(i % Cout_pad);
-        const long long t = i / Cout_pad;
-        const int tap = (int)(t % kk);
-        const int c = (int)(t / kk);
-        const float v = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
-        unsigned short hi, lo;
-        split2(v, s, hi, lo);
-        const long long o = (i >> 5) * 64 + (i & 31);
-        planes[o] = hi;
-        planes[o + 32] = lo;
-    }
-}
-
 // max |finite element| over the first C channels of an NHWC tensor with pitch: bit pattern, folded with atomicMax
 // (order independent -> deterministic) into a word the caller has zeroed (or that already holds a lower bound)
 // one atomic per BLOCK (waves folded through LDS), and only when it would raise the word
@@ -1584,6 +1481,162 @@ __global__ void amax_merge_kernel(unsigned* __restrict__ dst, const unsigned* __
     if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned v = *src; if (v) atomicMax(dst, v); }
 }
 
+// ---- filter maximum without atomics: stage 1 leaves one maximum per block, stage 2 lives in the split kernels' prologue
+constexpr int AMAX_PART_MAX = 1024;
+__global__ __launch_bounds__(256) void amax_partials_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ part) {
+    __shared__ unsigned wmax[4];
+    unsigned m = 0u;
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned b = __float_as_uint(v[e]) & 0x7fffffffu;
+            if (b < 0x7f800000u && b > m) m = b;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+        const unsigned b = __float_as_uint(x[(n4 << 2) + threadIdx.x]) & 0x7fffffffu;
+        if (b < 0x7f800000u && b > m) m = b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        part[blockIdx.x] = a > b ? a : b;
+    }
+}
+// every block folds the <= 1024 block maxima (4 KiB out of L2); block 0 publishes the result for the conv kernel
+__device__ __forceinline__ unsigned amax_fold_partials(const unsigned* __restrict__ part, int nparts, unsigned* __restrict__ out) {
+    __shared__ unsigned wmax[4];
+    unsigned m = 0u;
+    for (int i = threadIdx.x; i < nparts; i += 256) { const unsigned v = part[i]; m = v > m ? v : m; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    const unsigned v = a > b ? a : b;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out = v;
+    return v;
+}
+__global__ __launch_bounds__(256) void f16x2_split_filter_folded_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                                        long long n, const unsigned* __restrict__ part, int nparts,
+                                                                        unsigned* __restrict__ amax_out) {
+    const unsigned amax = amax_fold_partials(part, nparts, amax_out);
+    const float s = __uint_as_float(f16x2_scale_exp(amax) << 23);
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        unsigned short hi, lo;
+        split2(w[i], s, hi, lo);
+        const long long o = (i >> 5) * 64 + (i & 31);
+        planes[o] = hi;
+        planes[o + 32] = lo;
+    }
+}
+__global__ __launch_bounds__(256) void f16x2_transpose_split_filter_folded_kernel(const float* __restrict__ w,
+                                                                                  unsigned short* __restrict__ planes, int Cout, int Cin,
+                                                                                  int kk, int Cout_pad, const unsigned* __restrict__ part,
+                                                                                  int nparts, unsigned* __restrict__ amax_out) {
+    const unsigned amax = amax_fold_partials(part, nparts, amax_out);
+    const float s = __uint_as_float(f16x2_scale_exp(amax) << 23);
+    const long long total = (long long)Cin * kk * Cout_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % Cout_pad);
+        const long long t = i / Cout_pad;
+        const int tap = (int)(t % kk);
+        const int c = (int)(t / kk);
+        const float v = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
+        unsigned short hi, lo;
+        split2(v, s, hi, lo);
+        const long long o = (i >> 5) * 64 + (i & 31);
+        planes[o] = hi;
+        planes[o + 32] = lo;
+    }
+}
+
+// ---- inference: a prepared filter buffer is refreshed only when the filter's BITS changed (exact 64-bit positional
+// checksum, order independent), decided on the device: no host sync, no version counters to trust.
+//   header words: [0] max|w| bits  [1] scratch of the conv call  [2..3] checksum  [4] valid  [5] ticket
+constexpr int FP_PARTS = 256;
+__global__ __launch_bounds__(256) void filter_fingerprint_kernel(const float* __restrict__ w, long long n,
+                                                                 unsigned* __restrict__ part_max,
+                                                                 unsigned long long* __restrict__ part_sum) {
+    __shared__ unsigned wmax[4];
+    __shared__ unsigned long long wsum[4];
+    unsigned m = 0u;
+    unsigned long long cs = 0ull;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const unsigned bits = __float_as_uint(w[i]);
+        cs += (unsigned long long)bits * (2ull * (unsigned long long)i + 1ull) + 0x9e3779b97f4a7c15ull;
+        const unsigned b = bits & 0x7fffffffu;
+        if (b < 0x7f800000u && b > m) m = b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+        cs += __shfl_xor(cs, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wsum[threadIdx.x >> 6] = cs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        part_max[blockIdx.x] = a > b ? a : b;
+        part_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+}
+__global__ __launch_bounds__(256) void f16x2_split_filter_if_changed_kernel(const float* __restrict__ w,
+                                                                            unsigned short* __restrict__ planes, long long n,
+                                                                            const unsigned* __restrict__ part_max,
+                                                                            const unsigned long long* __restrict__ part_sum,
+                                                                            int nparts, unsigned* __restrict__ hdr) {
+    __shared__ unsigned wmax[4];
+    __shared__ unsigned long long wsum[4];
+    unsigned m = threadIdx.x < nparts ? part_max[threadIdx.x] : 0u;
+    unsigned long long cs = threadIdx.x < nparts ? part_sum[threadIdx.x] : 0ull;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
+        m = o > m ? o : m;
+        cs += __shfl_xor(cs, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wsum[threadIdx.x >> 6] = cs; }
+    __syncthreads();
+    const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+    const unsigned amax = a > b ? a : b;
+    const unsigned long long sum = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    // every block reads the stored fingerprint BEFORE it takes its ticket; the last ticket holder rewrites the header
+    const unsigned long long stored = (unsigned long long)hdr[2] | ((unsigned long long)hdr[3] << 32);
+    const bool same = hdr[4] == 1u && stored == sum && hdr[0] == amax;
+    if (!same) {
+        const float s = __uint_as_float(f16x2_scale_exp(amax) << 23);
+        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            unsigned short hi, lo;
+            split2(w[i], s, hi, lo);
+            const long long o = (i >> 5) * 64 + (i & 31);
+            planes[o] = hi;
+            planes[o + 32] = lo;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(hdr + 5, 1u);
+        if (t == gridDim.x - 1) {
+            hdr[0] = amax; hdr[2] = (unsigned)sum; hdr[3] = (unsigned)(sum >> 32); hdr[4] = 1u;
+            hdr[5] = 0u;
+        }
+    }
+}
+
 int g_f16x2_shape = 16;          // MFMA shape of the f16x2 kernels: 32 (32x32x16) or 16 (16x16x32); Y4_F16X2_SHAPE overrides
 
 template <int BM, int BN, int WM, int WN, bool TR, int MS, bool APL = false>
@@ -1616,9 +1669,6 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
         g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
     }
     size_t smem = (size_t)gather_rowm_off<BM, BN, WM, WN, MS>() + BM * sizeof(int);
-#if Y4_STAMPS
-    if (const char* e = getenv("Y4_EXTRA_LDS")) smem += (size_t)atoi(e);      // diagnostic: lower the occupancy
-#endif
     auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS, APL>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1742,19 +1792,53 @@ int f16x2_wgrad(const WgradGeom& g, hipStream_t st) {
     return launch_wgrad_f16x2<64, 64, 32>(g, st);
 }
 
-int f16x2_split_filter(const float* w, unsigned short* planes, long long n, const unsigned* amax, hipStream_t st) {
-    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(f16x2_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w, planes, n, amax);
+static int filter_amax_partials(const float* w, long long n, unsigned* part, hipStream_t st) {
+    if (reinterpret_cast<uintptr_t>(w) & 15) return -1;
+    long long blocks = (n / 4 + 1023) / 1024;
+    if (blocks < 1) blocks = 1;
+    if (blocks > AMAX_PART_MAX) blocks = AMAX_PART_MAX;
+    hipLaunchKernelGGL(amax_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, n, part);
+    return (int)blocks;
+}
+
+int f16x2_refresh_prepared(const float* w, void* prepared, int Cout, int K, hipStream_t st) {
+    const long long n = (long long)Cout * K;
+    unsigned* hdr = static_cast<unsigned*>(prepared);
+    unsigned* part_max = hdr + 16;                                            // [256] words, then [256] 64-bit sums
+    unsigned long long* part_sum = reinterpret_cast<unsigned long long*>(hdr + 16 + FP_PARTS);
+    unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(prepared) + 64 + 4096);
+    long long blocks = (n + 2047) / 2048;
+    if (blocks < 1) blocks = 1;
+    if (blocks > FP_PARTS) blocks = FP_PARTS;
+    hipLaunchKernelGGL(filter_fingerprint_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, n, part_max, part_sum);
+    Y4_CHECK_LAUNCH();
+    const int sb = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(f16x2_split_filter_if_changed_kernel, dim3(sb), dim3(256), 0, st, w, planes, n, part_max, part_sum,
+                       (int)blocks, hdr);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
 
-int f16x2_transpose_split_filter(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
-                                 const unsigned* amax, hipStream_t st) {
+int f16x2_filter_planes(const float* w, unsigned short* planes, int Cout, int K, unsigned* amax_out, unsigned* part, hipStream_t st) {
+    const long long n = (long long)Cout * K;
+    const int np = filter_amax_partials(w, n, part, st);
+    if (np < 0) return Y4_ERR_SHAPE;
+    Y4_CHECK_LAUNCH();
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(f16x2_split_filter_folded_kernel, dim3(blocks), dim3(256), 0, st, w, planes, n, part, np, amax_out);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int f16x2_filter_planes_transposed(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
+                                   unsigned* amax_out, unsigned* part, hipStream_t st) {
+    const int np = filter_amax_partials(w, (long long)Cout * kk * Cin, part, st);
+    if (np < 0) return Y4_ERR_SHAPE;
+    Y4_CHECK_LAUNCH();
     const long long total = (long long)Cin * kk * Cout_pad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(f16x2_transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w, planes, Cout, Cin, kk, Cout_pad,
-                       amax);
+    hipLaunchKernelGGL(f16x2_transpose_split_filter_folded_kernel, dim3(blocks), dim3(256), 0, st, w, planes, Cout, Cin, kk,
+                       Cout_pad, part, np, amax_out);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -27,22 +27,12 @@ struct ConvGeom {
     int cls_slot0[5];             // classed launch: per-XCD slot ranges (each XCD gets 1/8 of EVERY class)
     unsigned long long src_total_bytes;   // whole source tensor; each block re-bases its 32-bit buffer window at its first image
     unsigned wt_bytes;            // filter extent for the buffer descriptor (< 4 GiB, checked on the host)
-    const unsigned short* wt_planes;   // split modes: filter pre-split into 16-bit planes [NP][N][K] (library scratch)
+    const unsigned short* wt_planes;   // split modes: filter pre-split into 16-bit planes (the call's workspace)
     // f16x2 mode: device words holding the bit pattern of max|finite element| of the gathered tensor / the filter
     // (NULL: operand taken unscaled); every element is multiplied by the power of two that brings that maximum
     // into [2^14, 2^15) before it is split into fp16 pieces, and the epilogue undoes both scales
     const unsigned* src_amax; const unsigned* wt_amax;
     unsigned* dst_amax;           // f16x2 forward, optional: max|finite output| folded in with atomicMax
-    // dgrad only: fold the BatchNorm-backward reduction of the layer whose output gradient this launch produces into the
-    // epilogue (the per-tile column sums of g = dx * act'(u) and g * xhat, u = gamma * xhat + beta, xhat = (y - mean) * invstd)
-    const float* bn_y;            // that layer's pre-BN tensor [M][bn_ld], same pixels / channels as dst
-    const float* bn_mean;
-    const float* bn_invstd;
-    const float* bn_gamma;
-    const float* bn_beta;
-    float* bn_part;               // [tiles][2][N] partial sums (nullptr: no fold)
-    int bn_ld, bn_act;
-    unsigned long long* stamps;   // diagnostic builds only (Y4_STAMPS): cycle sums per loop segment
     int src_planes;               // f16x2: the gathered tensor is already split: per pixel [Cs hi halfs][Cs lo halfs] (4 Cs bytes)
 };
 
@@ -63,9 +53,13 @@ struct WgradGeom {
 // conv_f16x2.hip
 int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts);
 int f16x2_wgrad(const WgradGeom& g, hipStream_t st);
-int f16x2_split_filter(const float* w, unsigned short* planes, long long n, const unsigned* amax, hipStream_t st);
-int f16x2_transpose_split_filter(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
-                                 const unsigned* amax, hipStream_t st);
+// prepared filter (inference): [64-B header][4 KiB of fingerprint partials][planes]; re-split only when the bits changed
+int f16x2_refresh_prepared(const float* w, void* prepared, int Cout, int K, hipStream_t st);
+// filter maximum + split in two launches without atomics or pre-zeroed words: per-block maxima into part[<= 1024], folded
+// by every block of the split kernel (block 0 leaves the result in *amax_out for the conv kernel's epilogue)
+int f16x2_filter_planes(const float* w, unsigned short* planes, int Cout, int K, unsigned* amax_out, unsigned* part, hipStream_t st);
+int f16x2_filter_planes_transposed(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
+                                   unsigned* amax_out, unsigned* part, hipStream_t st);
 int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st,
                 bool prezeroed = false);     // zeroes the word first unless the caller hands in a zeroed one
 int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st);

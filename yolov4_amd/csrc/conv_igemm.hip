@@ -657,10 +657,6 @@ void note_kernel(const char* fmt, ...) {
 }
 }
 namespace {
-// process-wide scratch arena for library temporaries (pre-split filters); set by y4_set_workspace
-void* g_scratch = nullptr;
-size_t g_scratch_bytes = 0;
-
 template <int BM, int BN, int WM, int WN, bool TR, int BKT = 32, int NP = 0>
 int launch_gather(const ConvGeom& g0, hipStream_t st) {
     constexpr bool SPLIT = NP > 0;
@@ -1740,36 +1736,22 @@ int y4_set_conv_mode(int mode) {
 }
 int y4_get_conv_mode(void) { return g_conv_mode; }
 
-int y4_set_workspace(void* ptr, size_t bytes) {
-    if (ptr && (reinterpret_cast<uintptr_t>(ptr) & 15)) return Y4_ERR_SHAPE;
-    g_scratch = ptr;
-    g_scratch_bytes = ptr ? bytes : 0;
-    return Y4_OK;
-}
+// Per-call workspace of the forward conv (modes 1-3): [64 B of amax words: [0] filter, [1] gathered tensor when the caller
+// gave none][4 KiB of per-block filter maxima][filter planes].  Nothing is shared between calls, so convs may be issued
+// from any number of streams / devices / threads at once.
+constexpr size_t FWD_WS_HDR = 64 + 4096;
 
-// scratch arena layout: 256 bytes of amax words (f16x2 mode: [0] filter, [1] gathered tensor when the caller gave none),
-// then the filter planes
-constexpr size_t SCRATCH_HDR = 1024;
-// Words 64..191 of the scratch header: a ring of pre-zeroed cells for the operand maxima the library takes itself (filters
-// on every call, activations without a producer-side cell).  One 512-B memset refills the ring every 128 uses instead of
-// one 4-B memset per use; a cell is consumed by the kernels enqueued right behind its amax pass, so stream order makes
-// the reuse safe (same one-stream-at-a-time rule as the arena itself).
-constexpr int AMAX_RING = 128;
-unsigned* next_zero_cell(hipStream_t st) {
-    static int idx = 0;
-    static void* owner = nullptr;
-    if (!g_scratch || g_scratch_bytes < SCRATCH_HDR) return nullptr;
-    unsigned* ring = static_cast<unsigned*>(g_scratch) + 64;
-    if (owner != g_scratch) { owner = g_scratch; idx = 0; }             // a new arena starts with a refill
-    if (idx % AMAX_RING == 0 && hipMemsetAsync(ring, 0, AMAX_RING * sizeof(unsigned), st) != hipSuccess) return nullptr;
-    return ring + (idx++ % AMAX_RING);
+size_t y4_conv2d_fwd_workspace(int Cin, int Cout, int k) {
+    if (Cin <= 0 || Cout <= 0 || k <= 0) return 0;
+    return FWD_WS_HDR + (size_t)Cout * k * k * Cin * 6;
 }
 
 static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int ldy,
                          int B, int H, int W, int Cin, int Cout, int k, int stride,
                          const float* scale, const float* shift, int act,
                          const float* residual, int ldr, float* stats, int* nparts, const unsigned* x_amax,
-                         unsigned* y_amax, void* stream, void* w_prepared = nullptr) {
+                         unsigned* y_amax, void* workspace, size_t workspace_bytes, void* stream,
+                         void* w_prepared = nullptr) {
     if (!x || (!w && !w_prepared) || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1788,11 +1770,11 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cin; g.act = act;
     if (w_prepared) {
-        // filter already split (y4_conv2d_prepare_filter_f32): [word 0: max|w| bits][word 1: scratch][.. 64 B][planes]
+        // filter already split (y4_conv2d_prepare_filter_f32): [word 0: max|w| bits][word 1: scratch][.. 64 B][4 KiB][planes]
         if (g_conv_mode != 3) return Y4_ERR_SHAPE;
         if (reinterpret_cast<uintptr_t>(w_prepared) & 15) return Y4_ERR_SHAPE;
         unsigned* hdr = static_cast<unsigned*>(w_prepared);
-        g.wt_planes = reinterpret_cast<unsigned short*>(static_cast<char*>(w_prepared) + 64);
+        g.wt_planes = reinterpret_cast<unsigned short*>(static_cast<char*>(w_prepared) + 64 + 4096);
         if (!x_amax) {
             const int rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, hdr + 1, y4_stream(stream));
             if (rc != Y4_OK) return rc;
@@ -1803,26 +1785,21 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
     }
     if (g_conv_mode != 0) {
         const long long nw = (long long)Cout * g.K;
-        if (!g_scratch || g_scratch_bytes < SCRATCH_HDR + (size_t)nw * 6) return Y4_ERR_WORKSPACE;   // y4_set_workspace() first
-        unsigned* hdr = static_cast<unsigned*>(g_scratch);
-        unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(g_scratch) + SCRATCH_HDR);
+        if (!workspace) return Y4_ERR_NULL;
+        if (workspace_bytes < y4_conv2d_fwd_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+        if (reinterpret_cast<uintptr_t>(workspace) & 15) return Y4_ERR_SHAPE;
+        unsigned* hdr = static_cast<unsigned*>(workspace);
+        unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + FWD_WS_HDR);
         g.wt_planes = planes;
         if (g_conv_mode == 3) {
-            unsigned* wcell = next_zero_cell(y4_stream(stream));
-            if (!wcell) return Y4_ERR_LAUNCH;
-            int rc = y4::amax_launch(w, g.K, Cout, g.K, wcell, y4_stream(stream), true);
-            if (rc != Y4_OK) return rc;
-            rc = y4::f16x2_split_filter(w, planes, nw, wcell, y4_stream(stream));
+            int rc = y4::f16x2_filter_planes(w, planes, Cout, g.K, hdr, hdr + 16, y4_stream(stream));
             if (rc != Y4_OK) return rc;
             if (!x_amax) {                                  // no producer-side maximum: one extra pass over the input
-                unsigned* xcell = next_zero_cell(y4_stream(stream));
-                if (!xcell) return Y4_ERR_LAUNCH;
-                rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, xcell, y4_stream(stream), true);
+                rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, hdr + 1, y4_stream(stream));
                 if (rc != Y4_OK) return rc;
-                x_amax = xcell;
+                x_amax = hdr + 1;
             }
-            g.src_amax = x_amax; g.wt_amax = wcell; g.dst_amax = y_amax;
-            g.stamps = reinterpret_cast<unsigned long long*>(hdr + 16);      // scratch header words 64..127 (diagnostic builds)
+            g.src_amax = x_amax; g.wt_amax = hdr; g.dst_amax = y_amax;
             return y4::f16x2_gather(g, false, y4_stream(stream), nparts);
         }
         const int blocks = (int)((nw + 255) / 256 > 4096 ? 4096 : (nw + 255) / 256);
@@ -1836,9 +1813,10 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
 int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                       int B, int H, int W, int Cin, int Cout, int k, int stride,
                       const float* scale, const float* shift, int act,
-                      const float* residual, int ldr, const unsigned* x_amax, unsigned* y_amax, void* stream) {
+                      const float* residual, int ldr, const unsigned* x_amax, unsigned* y_amax,
+                      void* workspace, size_t workspace_bytes, void* stream) {
     return conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, scale, shift, act, residual, ldr, nullptr,
-                         nullptr, x_amax, y_amax, stream);
+                         nullptr, x_amax, y_amax, workspace, workspace_bytes, stream);
 }
 
 int y4_amax_f32(const float* x, int ldx, long long M, int C, unsigned* amax_bits, void* stream) {
@@ -1865,12 +1843,12 @@ size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k
 int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                               int B, int H, int W, int Cin, int Cout, int k, int stride,
                               float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
-                              void* stream) {
+                              void* workspace, size_t workspace_bytes, void* stream) {
     if (!partials || !nparts_host) return Y4_ERR_NULL;
     if (partial_bytes < y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;
     int np = 0;
     const int rc = conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, nullptr, nullptr, Y4_ACT_LINEAR,
-                                 nullptr, 0, partials, &np, x_amax, nullptr, stream);
+                                 nullptr, 0, partials, &np, x_amax, nullptr, workspace, workspace_bytes, stream);
     if (rc != Y4_OK) return rc;
     *nparts_host = np;
     return Y4_OK;
@@ -1879,20 +1857,14 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
 size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
     const size_t cp = (size_t)((Cout + 31) / 32) * 32;
     // fp32 transposed filter (4 B), 3 bf16 planes (6 B) or 2 fp16 planes (4 B) per element, + 64 B of amax words
-    return (size_t)Cin * k * k * cp * 6 + 64;
+    // + 4 KiB of per-block filter maxima
+    return (size_t)Cin * k * k * cp * 6 + 64 + 4096;
 }
-
-struct BnFold {                                            // see ConvGeom::bn_*
-    const float *y, *mean, *invstd, *gamma, *beta;
-    int ld, act;
-    float* part;
-    int* nparts;
-};
 
 static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx, int lddx,
                            int B, int H, int W, int Cin, int Cout, int k, int stride,
                            void* workspace, size_t workspace_bytes, const unsigned* dy_amax, int dy_is_planes,
-                           const float* residual, int ldr, void* stream, const BnFold* fold = nullptr) {
+                           const float* residual, int ldr, void* stream) {
     if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1906,13 +1878,10 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     const long long total = (long long)Cin * k * k * Cout_pad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)total * 6);
-    unsigned* wamax = hdr;
+    unsigned* wamax = hdr;                                 // the call's own words: nothing shared between calls
     if (g_conv_mode == 3) {
-        unsigned* wcell = next_zero_cell(st);              // (no arena registered: the call's own header word + a memset)
-        wamax = wcell ? wcell : hdr;
-        int rc = y4::amax_launch(w, (long long)k * k * Cin, Cout, k * k * Cin, wamax, st, wcell != nullptr);
-        if (rc != Y4_OK) return rc;
-        rc = y4::f16x2_transpose_split_filter(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad, wamax, st);
+        const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad,
+                                                          wamax, hdr + 16, st);
         if (rc != Y4_OK) return rc;
     } else if (g_conv_mode != 0)
         hipLaunchKernelGGL(transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w,
@@ -1944,12 +1913,7 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
             dy_amax = hdr + 1;
         }
         g.src_amax = dy_amax; g.wt_amax = wamax;
-        if (g_scratch && g_scratch_bytes >= SCRATCH_HDR) g.stamps = reinterpret_cast<unsigned long long*>(static_cast<unsigned*>(g_scratch) + 16);
-        if (fold) {
-            g.bn_y = fold->y; g.bn_ld = fold->ld; g.bn_mean = fold->mean; g.bn_invstd = fold->invstd;
-            g.bn_gamma = fold->gamma; g.bn_beta = fold->beta; g.bn_act = fold->act; g.bn_part = fold->part;
-        }
-        return y4::f16x2_gather(g, true, st, fold ? fold->nparts : nullptr);
+        return y4::f16x2_gather(g, true, st, nullptr);
     }
     return dispatch_gather<true>(g, st);
 }
@@ -1971,7 +1935,7 @@ int y4_last_conv_kernel(char* buf, int cap) {
 
 size_t y4_conv2d_prepared_bytes(int Cout, int K) {
     if (Cout <= 0 || K <= 0) return 0;
-    return 64 + (size_t)Cout * (size_t)K * 4;
+    return 64 + 4096 + (size_t)Cout * (size_t)K * 4;
 }
 
 int y4_conv2d_prepare_filter_f32(const float* w, int Cout, int K, void* prepared, size_t prepared_bytes, void* stream) {
@@ -1979,11 +1943,7 @@ int y4_conv2d_prepare_filter_f32(const float* w, int Cout, int K, void* prepared
     if (Cout <= 0 || K <= 0 || (K & 31)) return Y4_ERR_SHAPE;
     if (prepared_bytes < y4_conv2d_prepared_bytes(Cout, K)) return Y4_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(prepared) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) return Y4_ERR_SHAPE;
-    unsigned* hdr = static_cast<unsigned*>(prepared);
-    int rc = y4::amax_launch(w, K, Cout, K, hdr, y4_stream(stream));
-    if (rc != Y4_OK) return rc;
-    return y4::f16x2_split_filter(w, reinterpret_cast<unsigned short*>(static_cast<char*>(prepared) + 64),
-                                  (long long)Cout * K, hdr, y4_stream(stream));
+    return y4::f16x2_refresh_prepared(w, prepared, Cout, K, y4_stream(stream));
 }
 
 int y4_conv2d_fwd_prepared_f32(const float* x, int ldx, void* w_prepared, float* y, int ldy,
@@ -1992,35 +1952,7 @@ int y4_conv2d_fwd_prepared_f32(const float* x, int ldx, void* w_prepared, float*
                                const float* residual, int ldr, const unsigned* x_amax, unsigned* y_amax, void* stream) {
     if (!w_prepared) return Y4_ERR_NULL;
     return conv_fwd_impl(x, ldx, nullptr, y, ldy, B, H, W, Cin, Cout, k, stride, scale, shift, act, residual, ldr, nullptr,
-                         nullptr, x_amax, y_amax, stream, w_prepared);
-}
-
-size_t y4_conv2d_dgrad_bnfold_partials(int B, int H, int W, int Cin) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return 0;
-    const long long M = (long long)B * H * W;
-    long long rows = (M + 63) / 64;
-    const long long per_img = (long long)B * (((long long)H * W + 127) / 128);
-    if (per_img > rows) rows = per_img;
-    return (size_t)rows * 2 * (size_t)Cin * sizeof(float);
-}
-
-int y4_conv2d_dgrad_bnfold_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
-                               int B, int H, int W, int Cin, int Cout, int k, int stride,
-                               void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
-                               const float* residual, int ldr,
-                               const float* bn_y, int bn_ld, const float* bn_mean, const float* bn_invstd,
-                               const float* bn_gamma, const float* bn_beta, int bn_act,
-                               float* bn_partials, size_t bn_partials_bytes, int* n_partials_host, void* stream) {
-    if (!bn_y || !bn_mean || !bn_invstd || !bn_gamma || !bn_beta || !bn_partials || !n_partials_host) return Y4_ERR_NULL;
-    // the fold lives in the epilogues of the 3x3 stride-1 f16x2 dgrad kernels (long K loops: the epilogue is cheap there)
-    if (g_conv_mode != 3 || k != 3 || stride != 1 || bn_ld < Cin) return Y4_ERR_SHAPE;
-    if (bn_partials_bytes < y4_conv2d_dgrad_bnfold_partials(B, H, W, Cin)) return Y4_ERR_WORKSPACE;
-    int nparts = 0;
-    const BnFold f{bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_ld, bn_act, bn_partials, &nparts};
-    const int rc = conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, dy_amax,
-                                   0, residual, ldr, stream, &f);
-    *n_partials_host = nparts;
-    return rc;
+                         nullptr, x_amax, y_amax, nullptr, 0, stream, w_prepared);
 }
 
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {

@@ -774,7 +774,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            int act, float* dy, int lddy, float* dgamma, float* dbeta,
                            long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                           unsigned* f16_planes, const float* pre_partials, int n_pre, void* stream) {
+                           unsigned* f16_planes, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
@@ -786,12 +786,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     const int nrows = stat_rows(M, rm.rpb);
     const long long rblocks = bn_blocks(M, C);
     int nb = 0;
-    if (pre_partials) {
-        // the two column sums were already taken, per tile, by the dgrad that produced dz (y4_conv2d_dgrad_bnfold_f32)
-        if (n_pre <= 0 || f16_planes) return Y4_ERR_SHAPE;
-        const int rc = fold_partials(pre_partials, n_pre, C, bacc, &nb, st);
-        if (rc != Y4_OK) return rc;
-    } else {
+    {
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((unsigned)rblocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz,
                            y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, nrows, part, f16_planes);
         Y4_CHECK_LAUNCH();
@@ -817,17 +812,7 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
                       unsigned* f16_planes, void* stream) {
     return bn_act_bwd_impl(dz, lddz, y, ldy, mean, invstd, gamma, beta, act, dy, lddy, dgamma, dbeta, M, C, workspace,
-                           workspace_bytes, out_amax, f16_planes, nullptr, 0, stream);
-}
-
-int y4_bn_act_bwd_presummed_f32(const float* dz, int lddz, const float* y, int ldy,
-                                const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                int act, float* dy, int lddy, float* dgamma, float* dbeta,
-                                long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                                const float* partials, int n_partials, void* stream) {
-    if (!partials) return Y4_ERR_NULL;
-    return bn_act_bwd_impl(dz, lddz, y, ldy, mean, invstd, gamma, beta, act, dy, lddy, dgamma, dbeta, M, C, workspace,
-                           workspace_bytes, out_amax, nullptr, partials, n_partials, stream);
+                           workspace_bytes, out_amax, f16_planes, stream);
 }
 
 static int colsum_rows(long long M) { return (int)(M < 1024 ? M : 1024); }

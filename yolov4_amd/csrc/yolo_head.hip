@@ -985,9 +985,9 @@ int y4_post_count_f32(float* prediction, int B, long long N, int n_classes, floa
     if (B <= 0 || N <= 0 || n_classes <= 0) return Y4_ERR_SHAPE;
     hipStream_t st = y4_stream(stream);
     if (hipMemsetAsync(counts, 0, (size_t)B * n_classes * 4, st) != hipSuccess) return Y4_ERR_LAUNCH;
-    if (5 + n_classes <= POST_MAX_NCH) {
-        const int pitch = (5 + n_classes) | 1;
-        const size_t smem = (size_t)POST_ROWS * pitch * 4 + (size_t)2 * n_classes * 4;
+    const int pitch = (5 + n_classes) | 1;
+    const size_t smem = (size_t)POST_ROWS * pitch * 4 + (size_t)2 * n_classes * 4;     // tile + the two histograms
+    if (5 + n_classes <= POST_MAX_NCH && smem <= 65536) {                             // (64 KiB: the default dynamic-LDS limit)
         const long long ntiles = ((long long)B * N + POST_ROWS - 1) / POST_ROWS;
         hipLaunchKernelGGL(post_count_tiled_kernel, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(256), smem, st,
                            prediction, B, N, n_classes, conf_thre, convert_xyxy, counts);
@@ -1017,9 +1017,9 @@ int y4_post_nms_f32(const float* prediction, int B, long long N, int n_classes, 
     int* cursor = reinterpret_cast<int*>(base + l.cursor);
     hipStream_t st = y4_stream(stream);
     if (hipMemsetAsync(cursor, 0, (size_t)nseg * 4, st) != hipSuccess) return Y4_ERR_LAUNCH;
-    if (5 + n_classes <= POST_MAX_NCH) {
-        const int pitch = (5 + n_classes) | 1;
-        const size_t smem = (size_t)POST_ROWS * pitch * 4;
+    const int pitch = (5 + n_classes) | 1;
+    const size_t smem = (size_t)POST_ROWS * pitch * 4;
+    if (5 + n_classes <= POST_MAX_NCH && smem <= 65536) {
         const long long ntiles = ((long long)B * N + POST_ROWS - 1) / POST_ROWS;
         hipLaunchKernelGGL(post_fill_tiled_kernel, dim3((unsigned)(ntiles < 2048 ? ntiles : 2048)), dim3(256), smem, st,
                            prediction, B, N, n_classes, conf_thre, seg_offsets, cursor, keys);

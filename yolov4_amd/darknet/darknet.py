@@ -57,7 +57,7 @@ class ConvBNAct(nn.Module):
         io = {}
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
-               'dres_put': dres_put, 'dres_take': dres_take, 'bn_src': getattr(x, 'y4_bnsrc', None),
+               'dres_put': dres_put, 'dres_take': dres_take,
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:
             use_batch_stats = self.training or n.running_mean is None
@@ -80,9 +80,6 @@ class ConvBNAct(nn.Module):
             w = self.conv.weight
         cfg['weight_param'] = self.conv.weight       # its gradient may be produced on the side stream (ops._wgrad_to_param)
         z = ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
-        if io.get('bn_src') is not None:
-            # rides on THIS tensor object only: any view / fork / concat slot loses it, so a consumer that sees it holds z itself
-            z.y4_bnsrc = (io['bn_src'], z.data_ptr(), tuple(z.shape), z.stride())
         return ops.tag_amax(z, io.get('z_amax'))
 
 

@@ -95,22 +95,6 @@ def krsc(w):
     return w if same else w.contiguous(memory_format=CL)
 
 
-_SCRATCH = {}
-
-
-def ensure_scratch(device, nbytes=64 << 20):
-    """Register the library's scratch arena (pre-split filter planes) once per device."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    buf = _SCRATCH.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
-        _SCRATCH[key] = buf
-    if _SCRATCH.get('active') != key or _SCRATCH.get('active_ptr') != buf.data_ptr():
-        check(lib().y4_set_workspace(_ptr(buf), buf.numel()), 'set_workspace')
-        _SCRATCH['active'] = key
-        _SCRATCH['active_ptr'] = buf.data_ptr()
-
-
 def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 16),), dtype=torch.uint8, device=device)
 
@@ -130,11 +114,12 @@ def f16x2_mode():
 
 def new_amax(device, n=1):
     """n (1 or 8) zeroed device words out of a ring of 8192; each half is re-zeroed (one tiny fill) when the ring enters
-    it, i.e. >= 4096 words (several training steps) after its cells were handed out."""
+    it, i.e. >= 4096 words (several training steps) after its cells were handed out.  Every cell carries the generation
+    of its half: `live()` tells a holder whether the words are still its own."""
     key = device.index if device.index is not None else torch.cuda.current_device()
     st = _AMAX['pool'].get(key)
     if st is None:
-        st = {'buf': torch.zeros(_AMAX['N'], dtype=torch.int32, device=device), 'i': 0}
+        st = {'buf': torch.zeros(_AMAX['N'], dtype=torch.int32, device=device), 'i': 0, 'gen': [0, 0]}
         _AMAX['pool'][key] = st
     half = _AMAX['N'] // 2
     i = (st['i'] + n - 1) // n * n                    # n-word blocks are n-aligned, so they never straddle a half
@@ -143,12 +128,28 @@ def new_amax(device, n=1):
     if i // half != (st['i'] - 1) // half or st['i'] == 0:
         h0 = i // half * half
         st['buf'][h0:h0 + half].zero_()
+        st['gen'][i // half] += 1                     # cells handed out of this half before now are dead
     st['i'] = i + n
-    return st['buf'][i:i + n]
+    cell = st['buf'][i:i + n]
+    cell.y4_gen = (st, i // half, st['gen'][i // half])
+    return cell
+
+
+def live(cell):
+    """cell if its words still belong to it, else None (its ring half was recycled: a tensor held across ~4096 cell
+    allocations -- cached features, many forwards before one backward).  The holder then takes the maximum again
+    (amax_raw / inside the library) instead of reading another tensor's.  Cells from elsewhere (amax_raw) never expire."""
+    if cell is None:
+        return None
+    g = getattr(cell, 'y4_gen', None)
+    if g is None:
+        return cell
+    st, half, gen = g
+    return cell if st['gen'][half] == gen else None
 
 
 def amax_of(t):
-    return getattr(t, 'y4_amax', None) if t is not None else None
+    return live(getattr(t, 'y4_amax', None)) if t is not None else None
 
 
 def tag_amax(t, cell):
@@ -176,30 +177,23 @@ def conv_out_hw(H, W, k, s):
 
 
 # ------------------------------------------------------------------ raw op wrappers (no autograd)
-# Kernels of this library write parameters (fused optimizers) and BatchNorm running statistics (training forward) through
-# raw pointers, which torch's version counters do not see: every such write bumps this epoch, and the inference caches
-# below key on it.
-WEIGHTS_EPOCH = [0]
-
-
-def bump_weights_epoch():
-    WEIGHTS_EPOCH[0] += 1
-
-
 def prepared_filter(param):
-    """Inference only (conv mode 3): the filter's maximum + fp16 planes, split once per parameter version and kept on the
-    parameter (y4_conv2d_prepare_filter_f32) instead of once per forward call."""
+    """Inference only (conv mode 3): the filter's maximum + fp16 planes live in a buffer kept on the parameter and are
+    REFRESHED on every call by y4_conv2d_prepare_filter_f32, which re-splits only when the filter's bits changed (exact
+    checksum taken on the device: `.data` writes, raw-pointer optimizer kernels and load_state_dict are all seen)."""
     w = krsc(param)
-    key = (WEIGHTS_EPOCH[0], param._version, w.data_ptr())
-    hit = getattr(param, '_y4_prepared', None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
     L = lib()
     Cout, K = w.shape[0], w.shape[1] * w.shape[2] * w.shape[3]
-    nbytes = L.y4_conv2d_prepared_bytes(Cout, K)
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    check(L.y4_conv2d_prepare_filter_f32(_ptr(w), Cout, K, _ptr(buf), nbytes, _stream()), 'conv2d_prepare_filter')
-    param._y4_prepared = (key, buf)
+    key = (w.data_ptr(), Cout, K, w.device)
+    hit = getattr(param, '_y4_prepared', None)
+    if hit is None or hit[0] != key:
+        nbytes = L.y4_conv2d_prepared_bytes(Cout, K)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        buf[:64].zero_()                              # header: "nothing prepared yet"
+        hit = (key, buf)
+        param._y4_prepared = hit
+    buf = hit[1]
+    check(L.y4_conv2d_prepare_filter_f32(_ptr(w), Cout, K, _ptr(buf), buf.numel(), _stream()), 'conv2d_prepare_filter')
     return buf
 
 
@@ -213,7 +207,6 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
         out = empty_nhwc(B, Cout, Ho, Wo, x.device, pad_to=out_pad)
     ldy = nhwc_pitch(out)
     w = krsc(w)
-    ensure_scratch(x.device)
     if Cin == 3:
         if k != 3 or s != 1 or residual is not None:
             raise Y4Error('Cin=3 is supported for the 3x3/s1 stem only')
@@ -230,9 +223,11 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
                                            _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _ptr(x_amax),
                                            _ptr(out_amax), _stream()), 'conv2d_fwd_prepared')
         return out
+    nbytes = L.y4_conv2d_fwd_workspace(Cin, Cout, k)
+    ws = _ws(nbytes, x.device)                  # the call's own filter planes: nothing is shared between calls
     check(L.y4_conv2d_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, B, H, W, Cin, Cout, k, s,
                               _ptr(scale), _ptr(shift), ACT_IDS[act], _ptr(residual), ldr, _ptr(x_amax), _ptr(out_amax),
-                              _stream()), 'conv2d_fwd')
+                              _ptr(ws), nbytes, _stream()), 'conv2d_fwd')
     return out
 
 
@@ -246,7 +241,6 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     y = empty_nhwc(B, Cout, Ho, Wo, x.device)
     ldy = nhwc_pitch(y)
     w = krsc(w)
-    ensure_scratch(x.device)
     pbytes = L.y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, s)
     part = _ws(pbytes, x.device)
     if Cin == 3:
@@ -259,8 +253,11 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     else:
         x, ldx = as_nhwc(x)
         n = ctypes.c_longlong(0)
+        nbytes = L.y4_conv2d_fwd_workspace(Cin, Cout, k)
+        cws = _ws(nbytes, x.device)
         check(L.y4_conv2d_fwd_bnstats_f32(_ptr(x), ldx, _ptr(w), _ptr(y), ldy, B, H, W, Cin, Cout, k, s,
-                                          _ptr(part), pbytes, ctypes.byref(n), _ptr(x_amax), _stream()), 'conv2d_fwd_bnstats')
+                                          _ptr(part), pbytes, ctypes.byref(n), _ptr(x_amax), _ptr(cws), nbytes, _stream()),
+              'conv2d_fwd_bnstats')
         nparts = n.value
     mean = torch.empty(Cout, device=x.device, dtype=torch.float32)
     invstd = torch.empty(Cout, device=x.device, dtype=torch.float32)
@@ -269,8 +266,6 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     check(L.y4_bn_finalize_partials_f32(_ptr(part), nparts, B * Ho * Wo, Cout, _ptr(mean), _ptr(invstd),
                                         _ptr(running_mean), _ptr(running_var), _ptr(nbt), float(momentum), float(eps),
                                         _ptr(ws), wsb, _stream()), 'bn_finalize_partials')
-    if running_mean is not None:
-        bump_weights_epoch()                   # running statistics written behind torch's back
     return y, mean, invstd
 
 
@@ -282,16 +277,7 @@ def last_conv_kernel():
     return buf.value.decode()
 
 
-# BatchNorm-backward column sums taken in the epilogue of the consuming 3x3 dgrad instead of by the reduce sweep.  Built,
-# parity-tested, and measured +-0 on the training step (34 of 107 layers qualify -- the 1x1 convs inside ResBlock units and
-# conv sets; their reduce sweeps cost 1.5 ms, the Mish' work in the issue-bound dgrad epilogues costs the same): opt-in.
-BN_FOLD = {'on': os.environ.get('Y4_BN_FOLD', '0') == '1', 'folded': 0, 'swept': 0}
-
-
-def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=False, bn_fold=None):
-    """bn_fold: the producer box of the BatchNorm+act layer whose output this conv consumed alone (ConvBNActFn.forward):
-    the kernel then also takes that layer's BatchNorm-backward column sums in its epilogue and the call returns
-    (dx, partials, n_partials)."""
+def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=False):
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
@@ -303,17 +289,6 @@ def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
-    if bn_fold is not None:
-        by, bld = as_nhwc(bn_fold['y'])
-        pbytes = L.y4_conv2d_dgrad_bnfold_partials(B, H, W, Cin)
-        part = torch.empty(pbytes // 4, dtype=torch.float32, device=dy.device)
-        n = ctypes.c_int(0)
-        check(L.y4_conv2d_dgrad_bnfold_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
-                                           _ptr(ws), nbytes, _ptr(dy_amax), _ptr(residual), ldr,
-                                           _ptr(by), bld, _ptr(bn_fold['mean']), _ptr(bn_fold['invstd']),
-                                           _ptr(bn_fold['gamma']), _ptr(bn_fold['beta']), ACT_IDS[bn_fold['act']],
-                                           _ptr(part), pbytes, ctypes.byref(n), _stream()), 'conv2d_dgrad_bnfold')
-        return dx, part, n.value
     check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
                                 _ptr(ws), nbytes, _ptr(dy_amax), 1 if dy_planes else 0, _ptr(residual), ldr, _stream()),
           'conv2d_dgrad')
@@ -399,8 +374,7 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
     return z
 
 
-def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None,
-                   pre=None):
+def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None):
     """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
     L = lib()
     B, C, H, W = y.shape
@@ -414,12 +388,6 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
     dgamma, dbeta = slot(dgamma_out), slot(dbeta_out)
     nbytes = L.y4_bn_workspace(B * H * W, C)
     ws = _ws(nbytes, y.device)
-    if pre is not None:                       # (partials, n): column sums already taken by the dgrad that produced dz
-        check(L.y4_bn_act_bwd_presummed_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
-                                            ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
-                                            _ptr(ws), nbytes, _ptr(out_amax), _ptr(pre[0]), int(pre[1]), _stream()),
-              'bn_act_bwd_presummed')
-        return dy, dgamma, dbeta
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
                               _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), _stream()), 'bn_act_bwd')
@@ -435,20 +403,6 @@ def bias_grad_raw(dy):
     ws = _ws(nbytes, dy.device)
     check(L.y4_bias_grad_f32(_ptr(dy), ld, B * H * W, C, _ptr(db), _ptr(ws), nbytes, _stream()), 'bias_grad')
     return db
-
-
-def bn_fold_cached(gamma, beta, rm, rv, eps):
-    """Inference only: the folded (scale, shift) of an eval-mode BatchNorm, recomputed when any of its four tensors changes."""
-    key = (WEIGHTS_EPOCH[0], gamma._version, beta._version, rm._version, rv._version, gamma.data_ptr(), rm.data_ptr(), float(eps))
-    hit = getattr(gamma, '_y4_fold', None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    val = bn_fold_raw(gamma, beta, rm, rv, eps)
-    try:
-        gamma._y4_fold = (key, val)
-    except AttributeError:
-        pass
-    return val
 
 
 def bn_fold_raw(gamma, beta, rm, rv, eps):
@@ -559,15 +513,7 @@ class ConvBNActFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         # conv mode 3: operand maxima travel with the tensors (see "operand maxima" above)
         f16 = f16x2_mode() and x.shape[1] != 3
-        # BatchNorm-backward fold: x is the untouched output of ONE BatchNorm+act layer (its producer box rides on the
-        # tensor) and this is a 3x3 stride-1 conv: the dgrad epilogue will take that layer's column sums (backward below)
-        src = cfg.get('bn_src')
-        ctx.bn_src = None
-        if (src is not None and BN_FOLD['on'] and f16 and k == 3 and s == 1 and bn and training and cfg.get('grad', True)
-                and not DY_PLANES['dgrad'] and x.data_ptr() == src[1] and tuple(x.shape) == src[2] and x.stride() == src[3]):
-            ctx.bn_src = src[0]
-        ctx.bn_box = None
-        x_amax = cfg.get('x_amax') if f16 else None
+        x_amax = live(cfg.get('x_amax')) if f16 else None
         z_amax = None
         io = cfg.get('io')
         if f16 and x_amax is None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
@@ -579,28 +525,24 @@ class ConvBNActFn(torch.autograd.Function):
             y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
                                                    cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax)
             if f16x2_mode():
-                z_amax = cfg.get('out_amax') if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
+                z_amax = live(cfg.get('out_amax')) if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
                 if z_amax is None:
                     z_amax = new_amax(x.device)
             z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
-            if io is not None and cfg.get('grad', True) and BN_FOLD['on']:
-                # producer box: what a sole 3x3 consumer needs to take this layer's BatchNorm-backward sums for it
-                ctx.bn_box = {'y': y, 'mean': mean, 'invstd': invstd, 'gamma': gamma.detach(), 'beta': beta.detach(),
-                              'act': act, 'slot': {}}
-                io['bn_src'] = ctx.bn_box
         elif bn:
             # no autograd in flight (val.py / detect.py): the filter planes and the BN fold are per-parameter-version caches
             frozen = not cfg.get('grad', True) and os.environ.get('Y4_NO_INFER_CACHE') != '1'
             wprep = prepared_filter(cfg['weight_param']) if (frozen and f16 and cfg.get('weight_param') is not None) else None
-            fold = bn_fold_cached if frozen else bn_fold_raw
-            scale, shift = fold(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
+            scale, shift = bn_fold_raw(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
             o = dest
             Ho, Wo = conv_out_hw(x.shape[2], x.shape[3], k, s)
             o = o if _slot_ok(o, (x.shape[0], weight.shape[0], Ho, Wo)) else None
             if f16:
-                z_amax = (cfg.get('out_amax') if o is not None else None) or new_amax(x.device)
+                z_amax = live(cfg.get('out_amax')) if o is not None else None
+                if z_amax is None:                   # (never truth-test a device tensor: that is a host sync)
+                    z_amax = new_amax(x.device)
             z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual, out=o, x_amax=x_amax, out_amax=z_amax,
                              w_prepared=wprep)
             ctx.mode = 'bn_eval'
@@ -624,6 +566,7 @@ class ConvBNActFn(torch.autograd.Function):
         f16 = f16x2_mode() and ctx.x_shape[1] != 3
         dy_amax = None
         dy_planes = False
+        x_amax = live(ctx.x_amax)                     # None if the ring recycled it since forward: wgrad takes its own pass
         if ctx.mode == 'bn_train':
             x, weight, y, mean, invstd, gamma, beta = ctx.saved_tensors
             gp, bp = cfg.get('gamma_param'), cfg.get('beta_param')
@@ -633,21 +576,9 @@ class ConvBNActFn(torch.autograd.Function):
             # conv mode 3: dy leaves the BatchNorm backward sweep already split into its two fp16 planes (DY_PLANES)
             planes = new_amax(dz.device, 8) if (f16 and DY_PLANES['dgrad'] and y.shape[1] % 32 == 0) else None
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
-            # column sums deposited by the sole consumer's dgrad -- valid only for the very tensor it produced, untouched
-            # (an accumulated / replaced gradient has another address or a bumped version counter)
-            pre = None
-            box = getattr(ctx, 'bn_box', None)
-            sums = box['slot'].pop('sums', None) if box is not None else None
-            if (sums is not None and planes is None and dz.data_ptr() == sums[2] and dz._version == sums[3]
-                    and tuple(dz.shape) == sums[4] and dz.stride() == sums[5]):
-                pre = (sums[0], sums[1])
-            if box is not None:
-                box.clear()                   # plain ctx attributes outlive the node's saved tensors: drop the references
-                ctx.bn_box = None             # to y / mean / invstd now, not when the whole graph dies (+27 GiB otherwise)
-            BN_FOLD['folded' if pre is not None else 'swept'] += 1
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                                gp.grad if sink else None, bp.grad if sink else None,
-                                               out_amax=None if planes is not None else dy_amax, planes=planes, pre=pre)
+                                               out_amax=None if planes is not None else dy_amax, planes=planes)
             dy_planes = planes is not None
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
@@ -674,32 +605,25 @@ class ConvBNActFn(torch.autograd.Function):
                 raise Y4Error('gradient wrt the network input (stem, Cin=3) is not implemented')
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
-            src = getattr(ctx, 'bn_src', None)
-            if src is not None and not dy_planes:
-                dx, part, nparts = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad,
-                                                  bn_fold=src)
-                src['slot']['sums'] = (part, nparts, dx.data_ptr(), dx._version, tuple(dx.shape), dx.stride())
-                ctx.bn_src = None
-            else:
-                dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad, dy_planes=dy_planes)
+            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad, dy_planes=dy_planes)
         elif skip_grad is not None:
             raise Y4Error('a parked skip gradient has no consumer (input of the 1x1 conv does not require grad)')
         dw = None
         if ctx.needs_input_grad[1]:
             param = cfg.get('weight_param')
             if _ASYNC['on'] and param is not None and param.requires_grad:
-                _wgrad_to_param(x, dy, param, k, s, ctx.x_amax, dy_amax, dy_planes)   # lands in param.grad on the side stream
+                _wgrad_to_param(x, dy, param, k, s, x_amax, dy_amax, dy_planes)   # lands in param.grad on the side stream
             elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
                 # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place
                 # (no temporary, no accumulate pass); the bucket is told directly, autograd gets None
                 param._y4_grad_fresh = False
-                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad, x_amax=ctx.x_amax, dy_amax=dy_amax,
+                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad, x_amax=x_amax, dy_amax=dy_amax,
                                      dy_planes=dy_planes)
                 if got is not param.grad:
                     param.grad.add_(got)
                 param._y4_grad_ready()
             else:
-                dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, x_amax=ctx.x_amax, dy_amax=dy_amax, dy_planes=dy_planes)
+                dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, x_amax=x_amax, dy_amax=dy_amax, dy_planes=dy_planes)
         dres = dz if ctx.has_res else None
         put = cfg.get('dres_put')
         if dres is not None and put is not None:

@@ -96,7 +96,6 @@ class _MultiTensorOptimizer(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        ops.bump_weights_epoch()               # parameters are rewritten through raw pointers: inference caches expire
         rows, key, hyper, hyper_idx, keep, dev = [], [], [], {}, [], None
         for gi, group in enumerate(self.param_groups):
             for p in group['params']:
