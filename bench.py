@@ -109,6 +109,23 @@ class ConvTimer:
             timer.sym = 'conv_stem_wgrad_kernel' if x.shape[1] == 3 else f'{kern}<{tn}, {tj}' + tail
             return 2.0 * B * Ho * Wo * Cout * x.shape[1] * k * k, (x.shape[1], Cout, k, s, x.shape[2])
 
+        # DMA-fed kernels over pre-split operands (conv_planes.hip): x / dy arrive as ops.Planes, stride 1 in backward
+        def f_fwd_p(xp, w, k, s, *a, **kw):
+            B, Cin, H, W = xp.shape
+            Ho, Wo = ops.conv_out_hw(H, W, k, s)
+            return 2.0 * B * Ho * Wo * w.shape[0] * Cin * k * k, (Cin, w.shape[0], k, s, H)
+
+        def f_dgrad_p(dyp, w, x_shape, k, *a, **kw):
+            B, Cout, Ho, Wo = dyp.shape
+            return 2.0 * B * Ho * Wo * Cout * x_shape[1] * k * k, (x_shape[1], Cout, k, 1, x_shape[2])
+
+        def f_wgrad_p(xp, dyp, w_shape, k, *a, **kw):
+            B, Cout, Ho, Wo = dyp.shape
+            return 2.0 * B * Ho * Wo * Cout * xp.shape[1] * k * k, (xp.shape[1], Cout, k, 1, xp.shape[2])
+
+        ops.conv_fwd_planes_bnstats_raw = bracket(ops.conv_fwd_planes_bnstats_raw, 'conv_fwd', f_fwd_p)
+        ops.conv_dgrad_planes_raw = bracket(ops.conv_dgrad_planes_raw, 'conv_dgrad', f_dgrad_p)
+        ops.conv_wgrad_planes_raw = bracket(ops.conv_wgrad_planes_raw, 'conv_wgrad', f_wgrad_p)
         ops.conv_fwd_raw = bracket(ops.conv_fwd_raw, 'conv_fwd', f_fwd)
         ops.conv_fwd_bnstats_raw = bracket(ops.conv_fwd_bnstats_raw, 'conv_fwd', f_fwd)   # conv + BN-stat epilogue + fold
         ops.conv_dgrad_raw = bracket(ops.conv_dgrad_raw, 'conv_dgrad', f_dgrad)
@@ -481,13 +498,17 @@ def main():
             summ = timer.summary()
             syms = timer.by_symbol()
             dsym = max(syms, key=lambda k: syms[k]['seconds'])       # ONE kernel symbol, as rocprofv3 --stats names it
-            fam_of = {'conv_wgrad': 'conv_wgrad', 'conv_stem_wgrad': 'conv_wgrad'}
+            fam_of = {'conv_wgrad': 'conv_wgrad', 'conv_stem_wgrad': 'conv_wgrad', 'wgrad_planes': 'wgrad_planes',
+                      'conv_planes': 'conv_planes'}
             dom = next((f for p_, f in fam_of.items() if dsym.startswith(p_)), None) or \
                 ('conv_dgrad' if ', true' in dsym else 'conv_fwd')
             mi = MODES[args.conv_mode]
             kname = {'conv_fwd': f"conv_gather_{mi['kk']}<..,false> (forward implicit GEMM; filter split, BN-stat fold kernels included)",
                      'conv_dgrad': f"conv_gather_{mi['kk']}<..,true> (dgrad implicit GEMM; filter transpose/split included)",
-                     'conv_wgrad': f"conv_wgrad_{mi['kk']} (+ slab reduce)"}[dom]
+                     'conv_wgrad': f"conv_wgrad_{mi['kk']} (+ slab reduce)",
+                     'conv_planes': 'conv_planes_mfma (DMA-fed forward AND stride-1 dgrad over pre-split operands; filter split, '
+                                    'BN-stat fold kernels included)',
+                     'wgrad_planes': 'wgrad_planes_mfma (DMA-fed wgrad over pre-split operands, transposed LDS reads; + slab reduce)'}[dom]
             # The roofline of the instruction stream that actually runs: a split mode spends `mfmas` dense 16-bit MFMAs per
             # fp32-grade product, so its ceiling in ALGORITHMIC flop/s is the 16-bit MFMA peak / mfmas; frac is then the
             # matrix-pipe utilisation at nominal clock (identical to executed flop/s over the 2.5 PFLOP/s dense peak).

@@ -127,6 +127,34 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
                               const unsigned* x_amax /* mode 3, nullable */,
                               void* workspace, size_t workspace_bytes /* as y4_conv2d_fwd_f32 */, void* stream);
 
+/* ---- conv mode 3 over PRE-SPLIT activations ("planes", csrc/conv_planes.hip): the input arrives as the two fp16 pieces
+ * of the f16x2 split, per pixel and 32-channel K tile [64 B: 32 hi halfs | 64 B: 32 scaled-lo halfs] (4 bytes per element,
+ * pitch 4 Cin bytes, Cin % 32 == 0), scaled by the power of two that *x_amax (an upper bound of max|x|) implies; that is
+ * the form the BatchNorm sweeps can emit directly, and the form LDS-DMA can stage without touching the VALU.
+ * y4_planes_split_f32 converts an fp32 NHWC tensor (tests, tensors produced by kernels that do not emit planes).
+ * y4_conv2d_fwd_planes_f32 = y4_conv2d_fwd_bnstats_f32 on such an input (raw output + per-256-row-tile column sums;
+ * partials may be NULL); workspace as y4_conv2d_fwd_f32.  Replaces the same nn.Conv2d, darknet/darknet.py:31-36,53-54. */
+int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, void* stream);
+int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,
+                             int B, int H, int W, int Cin, int Cout, int k, int stride,
+                             float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* dgrad / wgrad of a STRIDE-1 conv over planes (dy, and for wgrad also x, pre-split as above; Cin % 32 == 0, Cout % 32 == 0):
+ * the same arithmetic as y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 in conv mode 3.  dgrad runs the forward DMA kernel on the
+ * mirrored transposed filter (workspace: y4_conv2d_dgrad_workspace()); wgrad stages both operands pixel-major and takes its
+ * fragments through the hardware transpose read (split-K slabs in y4_conv2d_wgrad_planes_workspace() bytes, fixed-order
+ * reduce: deterministic).  Autograd of the same nn.Conv2d, darknet/darknet.py:31-36. */
+int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx, int lddx,
+                               int B, int H, int W, int Cin, int Cout, int k,
+                               void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
+                               const float* residual, int ldr, void* stream);
+size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k);
+int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, float* dw,
+                               int B, int H, int W, int Cin, int Cout, int k,
+                               void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
+                               void* stream);
+
 /* Stem conv (Cin = 3): x addressed as x[b*sxb + c*sxc + h*sxh + w*sxw] so both the NCHW
  * tensor the reference feeds (yolo/engine/build.py:60) and NHWC work without a copy.
  * bnstats_partials (nullable): [ceil(B*H*W/256)][2][Cout] column sums of the output, valid when
@@ -144,8 +172,6 @@ size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k);
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes, const unsigned* dy_amax /* mode 3, nullable */,
-                        int dy_is_planes /* mode 3: dy was written by y4_bn_act_bwd_f32(f16_planes) -- per pixel [Cout hi
-                           halfs][Cout lo halfs]; needs dy_amax = its word [5], lddy == Cout, Cout % 32 == 0 */,
                         const float* residual, int ldr, void* stream);
 
 /* wgrad: dw[Cout][k][k][Cin] = sum_{b,ho,wo} dy (x) x -- autograd of nn.Conv2d wrt weight.
@@ -154,8 +180,7 @@ size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, 
 int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes,
-                        const unsigned* x_amax, const unsigned* dy_amax /* mode 3, nullable */,
-                        int dy_is_planes /* as y4_conv2d_dgrad_f32 */, void* stream);
+                        const unsigned* x_amax, const unsigned* dy_amax /* mode 3, nullable */, void* stream);
 size_t y4_conv2d_stem_wgrad_workspace(int B, int H, int W, int Cout);
 int y4_conv2d_stem_wgrad_f32(const float* x, long long sxb, long long sxc, long long sxh, long long sxw,
                              const float* dy, int lddy, float* dw, int B, int H, int W, int Cout,
@@ -186,11 +211,15 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
                                 void* workspace, size_t workspace_bytes, void* stream);
 /* z = act(gamma*(y-mean)*invstd + beta) + residual   (residual may be NULL).
  * out_amax (nullable, device word): max|finite z| is folded into it with atomicMax (the caller zeroes it, or it
- * already holds the maximum of other parts of the same concat buffer) -- the operand maximum of conv mode 3. */
+ * already holds the maximum of other parts of the same concat buffer) -- the operand maximum of conv mode 3.
+ * z == NULL: measure only (max|z| into *out_amax, nothing stored).
+ * z_planes != 0: z (ldz == C, C % 32 == 0) receives the tensor PRE-SPLIT for the plane conv kernels -- per pixel and
+ * 32-channel K tile [64 B: hi halfs | 64 B: scaled lo halfs], 4 bytes per element -- scaled by the power of two that
+ * *out_amax implies; *out_amax must already hold max|z| or an upper bound (a measure-only call on the same arguments). */
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, unsigned* out_amax, void* stream);
+                      long long M, int C, unsigned* out_amax, int z_planes, void* stream);
 /* Backward of the two ops above wrt y, gamma, beta given dz (grad wrt z; the residual branch
  * receives dz itself).  dy may alias dz.  workspace: y4_bn_workspace(M, C) bytes. */
 int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
@@ -198,11 +227,10 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,
                       long long M, int C, void* workspace, size_t workspace_bytes,
                       unsigned* out_amax /* nullable: max|finite dy|, as above */,
-                      unsigned* f16_planes /* nullable, 8 zeroed device words, conv mode 3: dy is written as the two fp16
-                         pieces of the f16x2 split -- per pixel [C hi halfs][C scaled-lo halfs] in the 4C bytes of its
-                         row (lddy == C, C % 32 == 0) -- scaled by a bound of max|dy| derived before the sweep; word [5]
-                         receives that bound and serves as dy_amax of y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 with
-                         dy_is_planes = 1 */,
+                      unsigned* f16_planes /* nullable, 8 zeroed device words, conv mode 3: dy is written PRE-SPLIT for the
+                         plane conv kernels (layout as y4_bn_act_fwd_f32 z_planes; lddy == C, C % 32 == 0), scaled by a
+                         bound of max|dy| derived before the sweep; word [5] receives that bound and serves as dy_amax
+                         of y4_conv2d_dgrad_planes_f32 / y4_conv2d_wgrad_planes_f32 */,
                       void* stream);
 /* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249): two fixed-order stages, no atomics
  * (deterministic).  workspace: y4_bias_grad_workspace(M, C) bytes */

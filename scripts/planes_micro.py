@@ -1,0 +1,78 @@
+# -*- coding: utf-8 -*-
+"""A/B on one box: DMA-fed plane kernels (conv_planes.hip) vs the register-staged f16x2 kernels on the layer shapes of the
+bs = 64 @608 step.  Interleaved rounds in one process (guide rule 24); both arms include the per-call filter split."""
+import json
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+sys.path.insert(0, 'tests')
+from yolov4_amd import ops  # noqa: E402
+
+SHAPES = [  # ci, co, k, s, H
+    (128, 128, 3, 1, 76), (256, 256, 3, 1, 38), (512, 512, 3, 1, 19), (128, 256, 3, 1, 76), (256, 512, 3, 1, 38),
+    (512, 1024, 3, 1, 19), (64, 64, 3, 1, 152), (256, 128, 1, 1, 76), (512, 256, 1, 1, 38), (1024, 512, 1, 1, 19),
+    (128, 128, 1, 1, 76), (256, 256, 1, 1, 38), (128, 256, 3, 2, 152), (256, 512, 3, 2, 76),
+]
+
+
+MODE = 'fwd'
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    global MODE
+    MODE = sys.argv[2] if len(sys.argv) > 2 else 'fwd'
+    dev = torch.device('cuda:0')
+    out = []
+    for ci, co, k, s, H in SHAPES:
+        x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(co, ci, k, k, device=dev) / np.sqrt(ci * k * k)).contiguous(memory_format=torch.channels_last)
+        xa = ops.amax_raw(x)
+        xp = ops.planes_split_raw(x, xa)
+        Ho0 = (H + 2 * ((k - 1) // 2) - k) // s + 1
+        if MODE == 'fwd':
+            arms = {'regstage': lambda: ops.conv_fwd_bnstats_raw(x, w, k, s, None, None, None, 0.1, 1e-5, x_amax=xa),
+                    'planes': lambda: ops.conv_fwd_planes_raw(xp, w, k, s)}
+        else:
+            if s != 1:
+                continue
+            dy = torch.randn(B, co, Ho0, Ho0, device=dev).contiguous(memory_format=torch.channels_last)
+            da = ops.amax_raw(dy)
+            dyp = ops.planes_split_raw(dy, da)
+            if MODE == 'dgrad':
+                arms = {'regstage': lambda: ops.conv_dgrad_raw(dy, w, (B, ci, H, H), k, s, dy_amax=da),
+                        'planes': lambda: ops.conv_dgrad_planes_raw(dyp, w, (B, ci, H, H), k)}
+            else:
+                arms = {'regstage': lambda: ops.conv_wgrad_raw(x, dy, (co, ci, k, k), k, s, x_amax=xa, dy_amax=da),
+                        'planes': lambda: ops.conv_wgrad_planes_raw(xp, dyp, (co, ci, k, k), k)}
+        for f in arms.values():
+            f()
+        torch.cuda.synchronize()
+        ts = {a: [] for a in arms}
+        for _ in range(6):
+            for a, f in arms.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    f()
+                e1.record()
+                torch.cuda.synchronize()
+                ts[a].append(e0.elapsed_time(e1) / 5)
+        Ho = (H + 2 * ((k - 1) // 2) - k) // s + 1
+        fl = 2.0 * B * Ho * Ho * co * ci * k * k
+        row = {'shape': f'{ci}->{co} k{k} s{s} @{H}', 'gflop': fl / 1e9}
+        for a in arms:
+            med = float(np.median(ts[a]))
+            row[a + '_ms'] = round(med, 4)
+            row[a + '_tflops'] = round(fl / med / 1e9, 1)
+        row['speedup'] = round(row['regstage_ms'] / row['planes_ms'], 3)
+        print(json.dumps(row), flush=True)
+        out.append(row)
+        del x, w, xp
+
+
+if __name__ == '__main__':
+    main()

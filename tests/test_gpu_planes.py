@@ -1,0 +1,136 @@
+# -*- coding: utf-8 -*-
+"""DMA-fed conv kernels over pre-split operands (csrc/conv_planes.hip) against torch CPU and against the register-staged
+f16x2 kernels they replace: same arithmetic (same scales, same pieces, same three MFMAs per product), so results agree to
+accumulation order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import recipe
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'gpu tests need an MI355X'
+    import yolov4_amd
+    assert yolov4_amd.lib().y4_device_count() >= 1
+    assert yolov4_amd.lib().y4_get_conv_mode() == 3      # f16x2
+    return torch.device('cuda:0')
+
+
+def cl(t, dev):
+    return t.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+PLANE_CASES = [
+    # B, Cin, Cout, k, s, H, W
+    (2, 32, 64, 3, 1, 9, 9),          # M = 162 < one tile, N = 64 < BN
+    (3, 64, 128, 3, 2, 13, 13),       # odd size, stride 2
+    (2, 128, 128, 1, 1, 12, 12),
+    (2, 64, 32, 1, 1, 20, 20),
+    (5, 512, 256, 1, 1, 7, 7),        # tiles span several images
+    (2, 128, 256, 3, 1, 19, 19),      # two N tiles, M = 722 (three tiles, ragged)
+    (1, 32, 36, 3, 1, 40, 40),        # Cout % 4 == 0 only
+    (2, 2048, 512, 1, 1, 5, 5),
+]
+
+
+@pytest.mark.parametrize('case', PLANE_CASES)
+def test_planes_forward_matches_torch_and_the_register_staged_kernel(dev, case):
+    from yolov4_amd import ops
+    B, ci, co, k, s, H, W = case
+    x = recipe.randn((B, ci, H, W), 7)
+    w = recipe.randn((co, ci, k, k), 8, 1.0 / np.sqrt(ci * k * k))
+    ref = F.conv2d(x.double(), w.double(), None, s, (k - 1) // 2)
+    xd, wd = cl(x, dev), cl(w, dev)
+    xp = ops.planes_split_raw(xd)
+    y, part, n = ops.conv_fwd_planes_raw(xp, wd, k, s)
+    torch.cuda.synchronize()
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    y0 = ops.conv_fwd_raw(xd, wd, k, s)
+    assert float((y - y0).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # column sums of the epilogue = sums of the stored result
+    M = y.shape[0] * y.shape[2] * y.shape[3]
+    assert n == (M + 255) // 256
+    ps = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()), dtype=torch.float32)[:n * 2 * co].view(n, 2, co).double().sum(0)
+    yy = y.double().cpu().permute(0, 2, 3, 1).reshape(-1, co)
+    assert torch.allclose(ps[0], yy.sum(0), rtol=1e-5, atol=1e-4 * float(yy.abs().max()))
+    assert torch.allclose(ps[1], (yy * yy).sum(0), rtol=1e-5, atol=1e-4 * float((yy * yy).max()))
+
+
+def test_planes_round_trip_is_the_f16x2_split(dev):
+    """hi + 2^-11 lo reproduces s x to 2^-22 relative; pad / zero rows stay zero."""
+    from yolov4_amd import ops
+    x = recipe.randn((2, 64, 6, 5), 3) * 37.0
+    x[0, :, 0, 0] = 0.0
+    xp = ops.planes_split_raw(cl(x, dev))
+    raw = xp.buf.cpu().numpy().reshape(2, 6, 5, 2, 2, 32, 2).copy()      # [b][h][w][K tile][hi|lo][32 ch][2 bytes]
+    h = raw.view(np.float16).reshape(2, 6, 5, 2, 2, 32).astype(np.float64)
+    amax = np.float32(np.abs(x.numpy()).max())
+    e = int((amax.view(np.uint32) >> 23) & 0xff)
+    s = 2.0 ** (268 - e - 127)
+    rec = (h[..., 0, :] + h[..., 1, :] / 2048.0).reshape(2, 6, 5, 64) / s
+    ref = x.permute(0, 2, 3, 1).double().numpy()
+    assert np.abs(rec - ref).max() <= 2.0 ** -21 * np.abs(ref).max()
+    assert (rec[0, 0, 0] == 0).all()
+
+
+BWD_CASES = [
+    # B, Cin, Cout, k, H, W            (stride 1)
+    (2, 64, 128, 3, 9, 9),
+    (3, 128, 128, 1, 12, 12),
+    (2, 128, 256, 3, 19, 19),         # two n tiles (wgrad), J = 1152: 4.5 j tiles
+    (5, 512, 256, 1, 7, 7),
+    (1, 32, 32, 3, 40, 40),           # one partial tile each way
+    (4, 256, 128, 3, 13, 11),         # non-square map, K-steps straddle rows and images
+]
+
+
+@pytest.mark.parametrize('case', BWD_CASES)
+def test_planes_dgrad_and_wgrad_match_torch_and_the_register_staged_kernels(dev, case):
+    from yolov4_amd import ops
+    B, ci, co, k, H, W = case
+    x = recipe.randn((B, ci, H, W), 17)
+    w = recipe.randn((co, ci, k, k), 18, 1.0 / np.sqrt(ci * k * k))
+    dy = recipe.randn((B, co, H, W), 19)
+    res = recipe.randn((B, ci, H, W), 20)
+    pad = (k - 1) // 2
+    dx_ref = F.conv_transpose2d(dy.double(), w.double(), None, 1, pad)
+    xp64 = F.pad(x.double(), (pad, pad, pad, pad))
+    dw_ref = torch.zeros(co, ci, k, k, dtype=torch.float64)
+    for r in range(k):
+        for q in range(k):
+            dw_ref[:, :, r, q] = torch.einsum('bnhw,bchw->nc', dy.double(), xp64[:, :, r:r + H, q:q + W])
+    xd, wd, dyd = cl(x, dev), cl(w, dev), cl(dy, dev)
+    xp, dyp = ops.planes_split_raw(xd), ops.planes_split_raw(dyd)
+    dx = ops.conv_dgrad_planes_raw(dyp, wd, (B, ci, H, W), k)
+    err = float((dx.double().cpu() - dx_ref).abs().max() / dx_ref.abs().max())
+    assert err < 2e-6, err
+    dx0 = ops.conv_dgrad_raw(dyd, wd, (B, ci, H, W), k, 1)
+    assert float((dx - dx0).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+    dxr = ops.conv_dgrad_planes_raw(dyp, wd, (B, ci, H, W), k, residual=cl(res, dev))
+    assert torch.allclose(dxr.cpu(), dx.cpu() + res, rtol=0, atol=1e-6 * float(dx_ref.abs().max()))
+    dw = ops.conv_wgrad_planes_raw(xp, dyp, (co, ci, k, k), k)
+    err = float((dw.double().cpu() - dw_ref).abs().max() / dw_ref.abs().max())
+    assert err < 3e-6, err
+    dw0 = ops.conv_wgrad_raw(xd, dyd, (co, ci, k, k), k, 1)
+    assert float((dw - dw0).abs().max()) <= 3e-6 * float(dw_ref.abs().max())
+
+
+def test_planes_wgrad_is_deterministic_and_splits_cover_every_pixel(dev):
+    """Split-K over pixel ranges with a fixed-order slab reduce: the same inputs twice give the same bits; a constant
+    dy = 1, x = 1 counts the pixels each filter tap sees (interior taps M, border taps fewer)."""
+    from yolov4_amd import ops
+    B, ci, co, k, H, W = 8, 64, 128, 3, 38, 38
+    x = torch.ones(B, ci, H, W)
+    dy = torch.ones(B, co, H, W)
+    xp, dyp = ops.planes_split_raw(cl(x, dev)), ops.planes_split_raw(cl(dy, dev))
+    dw1 = ops.conv_wgrad_planes_raw(xp, dyp, (co, ci, k, k), k).clone()
+    dw2 = ops.conv_wgrad_planes_raw(xp, dyp, (co, ci, k, k), k)
+    assert torch.equal(dw1, dw2)
+    cnt = torch.tensor([[(H - abs(r - 1)) * (W - abs(q - 1)) * B for q in range(3)] for r in range(3)], dtype=torch.float32)
+    assert torch.equal(dw1.cpu(), cnt.view(1, 1, 3, 3).expand(co, ci, 3, 3))

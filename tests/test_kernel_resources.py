@@ -28,8 +28,12 @@ def test_no_kernel_uses_scratch(src, flags):
     # the kernels the bs=64 training step launches most are in the table and within the 2-blocks-per-CU budget
     if src == 'conv_f16x2.hip':
         names = {r['name'].split('(')[0]: r for r in rows}
-        for k in ('void conv_gather_f16x2<128, 128, 2, 2, true, 16, false>', 'void conv_gather_f16x2<128, 128, 2, 2, false, 16, false>',
-                  'void conv3x3_halo_f16x2<128, true, 16, false>', 'void conv3x3_halo_f16x2<128, false, 16, false>',
-                  'void conv_wgrad_f16x2<128, 128, 16, false>'):
+        for k in ('void conv_gather_f16x2<128, 128, 2, 2, true, 16>', 'void conv_gather_f16x2<128, 128, 2, 2, false, 16>',
+                  'void conv3x3_halo_f16x2<128, true, 16>', 'void conv3x3_halo_f16x2<128, false, 16>',
+                  'void conv_wgrad_f16x2<128, 128, 16>'):
             assert k in names, k
             assert names[k]['vgprs'] + names[k]['agprs'] <= 256, (k, names[k])
+    if src == 'conv_planes.hip':                      # one 8-wave block per CU: 256 registers per lane
+        for r in rows:
+            if 'planes_mfma' in r['name']:
+                assert r['vgprs'] + r['agprs'] <= 256 and r['occupancy'] >= 2, r

@@ -39,18 +39,23 @@ PROTOTYPES = {
     'y4_last_conv_kernel': (I, [ctypes.c_char_p, I]),
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
     'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P, Z, P]),
+    'y4_planes_split_f32': (I, [P, I, L, I, P, P, P]),
+    'y4_conv2d_fwd_planes_f32': (I, [P, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P, Z, P]),
+    'y4_conv2d_dgrad_planes_f32': (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P, P, I, P]),
+    'y4_conv2d_wgrad_planes_workspace': (Z, [I, I, I, I, I, I]),
+    'y4_conv2d_wgrad_planes_f32': (I, [P, P, P, I, I, I, I, I, I, P, Z, P, P, P]),
     'y4_conv2d_stem_fwd_f32': (I, [P, L, L, L, L, P, P, I, I, I, I, I, P, P, I, P, P]),
     'y4_conv2d_dgrad_workspace': (Z, [I, I, I]),
-    'y4_conv2d_dgrad_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, I, P, I, P]),
+    'y4_conv2d_dgrad_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, I, P]),
     'y4_conv2d_wgrad_workspace': (Z, [I, I, I, I, I, I, I]),
-    'y4_conv2d_wgrad_f32': (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, Z, P, P, I, P]),
+    'y4_conv2d_wgrad_f32': (I, [P, I, P, I, P, I, I, I, I, I, I, I, P, Z, P, P, P]),
     'y4_conv2d_stem_wgrad_workspace': (Z, [I, I, I, I]),
     'y4_conv2d_stem_wgrad_f32': (I, [P, L, L, L, L, P, I, P, I, I, I, I, P, Z, P]),
     'y4_bn_workspace': (Z, [L, I]),
     'y4_bn_finalize_workspace': (Z, [I]),
     'y4_bn_finalize_partials_f32': (I, [P, L, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_stats_f32': (I, [P, I, L, I, P, P, P, P, P, F, F, P, Z, P]),
-    'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, P]),
+    'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, I, P]),
     'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, P]),
     'y4_bias_grad_workspace': (Z, [L, I]),
     'y4_bias_grad_f32': (I, [P, I, L, I, P, P, Z, P]),

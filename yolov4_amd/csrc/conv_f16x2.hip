@@ -107,8 +107,6 @@ constexpr int ROWB = 64;                                   // bytes per LDS row 
 // ==================================================================================== forward / dgrad
 // TRANSPOSED = false: source pixel = (hd*stride - pad + r, wd*stride - pad + q)      [forward]
 // TRANSPOSED = true : source pixel = ((hd + pad - r)/stride, (wd + pad - q)/stride)   [dgrad]
-// APL: the gathered tensor arrives pre-split (ConvGeom::src_planes: dy planes written by the BatchNorm backward sweep);
-//      its tile is then staged like the filter tile -- 16-B loads of each plane, ds_write_b128, no VALU.
 // LDS map of conv_gather_f16x2: [two staging buffers | re-used by the vector epilogue: 4 wave patches of
 // [WTM][WTN + 4] floats][row_m: BM ints]
 template <int BM, int BN, int WM, int WN, int MS>
@@ -118,10 +116,10 @@ __host__ __device__ constexpr int gather_rowm_off() {       // byte offset of ro
     return patches > stages ? patches : stages;
 }
 
-template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int MS, bool APL = false>
+template <int BM, int BN, int WM, int WN, bool TRANSPOSED, int MS>
 __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     constexpr int BK = 32;
-    constexpr int PA = APL ? (BM * 4 + 255) / 256 : BM / 32;   // A items per thread: 16-B plane chunks, or fp32 row chunks
+    constexpr int PA = BM / 32;                            // fp32 row chunks of the A tile per thread
     constexpr int NB = (BN * 8 + 255) / 256;               // 16-B chunks of the B tile per thread (both planes)
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MS, TN = WTN / MS;
@@ -177,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     const unsigned pix_bytes = (unsigned)g.lds_ * 4u;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-        const int row = APL ? (tid + 256 * p) >> 2 : p * 32 + lrow;
+        const int row = p * 32 + lrow;
         const int i = mt_local * BM + row;
         int b, hd, wd;
         if (!classed) {
@@ -195,13 +193,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
             const int hh = rem / wc;
             hd = 2 * hh + ph; wd = 2 * (rem - hh * wc) + pw;
         }
-        const int ach = APL ? ((tid + 256 * p) & 3) : kc;                      // 16-B chunk inside the K-tile row
+        const int ach = kc;                                // 16-B chunk inside the K-tile row
         if (ach == 0 && row < BM) row_m[row] = a_ok[p] ? (b * g.Hd + hd) * g.Wd + wd : -1;
         a_base[p] = (unsigned)(b - b_first) * (unsigned)(g.Hs * g.Ws) * pix_bytes + ach * 16u;
         if (!TRANSPOSED) { a_h[p] = hd * g.stride - g.pad; a_w[p] = wd * g.stride - g.pad; }
         else { a_h[p] = hd + g.pad; a_w[p] = wd + g.pad; }
-        if (APL) a_lds[p] = row < BM ? row * ROWB + ((ach ^ lds_swz<MS>(row)) << 4) : -1;
-        else a_lds[p] = row * ROWB + (((kc >> 1) ^ lds_swz<MS>(row)) << 4) + ((kc & 1) << 3);
+        a_lds[p] = row * ROWB + (((kc >> 1) ^ lds_swz<MS>(row)) << 4) + ((kc & 1) << 3);
     }
     unsigned b_off[NB];
     int b_lds[NB];
@@ -216,11 +213,9 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
         b_lds[i] = row < BN ? bpl * BN * ROWB + row * ROWB + ((ch ^ lds_swz<MS>(row)) << 4) : -1;
     }
 
-    f32x4 ra[APL ? 1 : PA];
-    u32x4 rap[APL ? PA : 1][2];                            // APL: hi / lo plane chunks
+    f32x4 ra[PA];
     u32x4 rb[NB];
     const int CC = g.Cs / BK;
-    const unsigned a_lo = (unsigned)g.Cs * 2u;             // APL: byte offset of the lo plane inside a pixel row
     int r = r0, q = q0, cc = 0;
     unsigned a_off[PA];
     auto tap_setup = [&]() {
@@ -242,16 +237,8 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     };
     tap_setup();
     auto load_tile = [&]() {
-        if constexpr (APL) {
 #pragma unroll
-            for (int p = 0; p < PA; ++p) {
-                rap[p][0] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u), 0);
-                rap[p][1] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u + a_lo), 0);
-            }
-        } else {
-#pragma unroll
-            for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
-        }
+        for (int p = 0; p < PA; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)(cc * BK) * 4u);
         const unsigned koff = (unsigned)((r * g.k + q) * CC + cc) * (BK * 4u);
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc, (int)b_off[i], (int)koff, 0);
@@ -261,14 +248,6 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
     auto store_tile = [&](int buf) {
         unsigned char* as = smem_b + buf * STAGE;
         unsigned char* bs = as + 2 * BM * ROWB;
-        if constexpr (APL) {
-#pragma unroll
-            for (int p = 0; p < PA; ++p)
-                if (a_lds[p] >= 0) {
-                    *reinterpret_cast<u32x4*>(as + a_lds[p]) = rap[p][0];
-                    *reinterpret_cast<u32x4*>(as + BM * ROWB + a_lds[p]) = rap[p][1];
-                }
-        } else
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             f32x4 v = ra[p];
@@ -526,9 +505,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_f16x2(const ConvGeom g) {
 // (Measured and dropped: an 8-wave "ping-pong" form -- one block per CU, two 4-wave groups taking alternate chunks, one
 // staging while the other runs its MFMAs -- was 1.5x SLOWER (64.8 vs 42.4 ms per step over all wgrad launches): the
 // kernel is bound by the VALU work of the operand split, and a ping-pong lets only half the waves do VALU at a time.)
-// APL: dy arrives pre-split (WgradGeom::dy_planes): threads 0-127 take the hi plane, 128-255 the lo plane; each owns a
-//      4-pixel x 8-channel block (4 x 16-B loads), transposes it with 16 v_perm_b32 and writes 8 channel rows of 8 B.
-template <int TN_, int TJ_, int MS, bool APL = false>
+template <int TN_, int TJ_, int MS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     constexpr int WTN = TN_ / 2, WTJ = TJ_ / 2;
     constexpr int MI = WTN / MS, MJ = WTJ / MS;
@@ -596,28 +573,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
         w_lds[e] = row * ROWB + (((pg >> 1) ^ lds_swz<MS>(row)) << 4) + ((pg & 1) << 3);
     }
 
-    // APL staging map of dy: plane, 4-pixel group, 8-channel group
-    const int apl = tid >> 7, apg = tid & 7, acg = (tid & 127) >> 3;
-    const bool ap_ok = APL && acg * 8 < TN_ && (n0 + acg * 8) < g.Cout;
-    const unsigned ap_off0 = ap_ok ? (unsigned)(apg * 4) * dy_pix_bytes + (unsigned)apl * (unsigned)g.Cout * 2u + (unsigned)(n0 + acg * 8) * 2u : OOB;
-    int ap_lds[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int row = acg * 8 + c;
-        ap_lds[c] = apl * TN_ * ROWB + row * ROWB + (((apg >> 1) ^ lds_swz<MS>(row)) << 4) + ((apg & 1) << 3);
-    }
     f32x4 ra[4], rb[4];
     int ld_chunk = 0;
     auto load_chunk = [&]() {
         const int pbase = (chunk0 + ld_chunk) * 32 + pg * 4;
-        if constexpr (APL) {
-            const int pb2 = (chunk0 + ld_chunk) * 32 + apg * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = ap_ok && pb2 + i < g.M;
-                ra[i] = y4_buf_load4(dy_rsrc, ok ? ap_off0 + (unsigned)i * dy_pix_bytes : OOB, (unsigned)ld_chunk * chunk_bytes);
-            }
-        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = an_ok && pbase + i < g.M;
@@ -651,24 +610,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
     };
     auto store_chunk = [&](int buf) {
         unsigned char* as = smem_b + buf * STAGE;
-        if constexpr (APL) {
-            if (acg * 8 < TN_) {
-                // ra[i] = 8 halfs (channels c0..c0+7) of pixel i; row c gets {px0, px1, px2, px3} of channel c
-                u32x4 v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = __builtin_bit_cast(u32x4, ra[i]);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const unsigned sel = (c & 1) ? 0x07060302u : 0x05040100u;      // upper / lower half of both dwords
-                    u32x2 o;
-                    o[0] = __builtin_amdgcn_perm(v[1][c >> 1], v[0][c >> 1], sel);
-                    o[1] = __builtin_amdgcn_perm(v[3][c >> 1], v[2][c >> 1], sel);
-                    *reinterpret_cast<u32x2*>(as + ap_lds[c]) = o;
-                }
-            }
-        } else {
-            if (a_act) split_store(ra, s_dy, as, TN_);
-        }
+        if (a_act) split_store(ra, s_dy, as, TN_);
         if (b_act) split_store(rb, s_x, as + 2 * TN_ * ROWB, TJ_);
     };
 
@@ -778,14 +720,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2(const WgradGeom g) {
 //   * per 9 taps a thread issues <= 10 activation loads and splits <= 40 values instead of 36 loads / 144 values.
 constexpr int HALO_ROWS = 304;                             // patch capacity (rows of 32 channels)
 
-template <int BN, bool TRANSPOSED, int MS, bool APL = false>
+template <int BN, bool TRANSPOSED, int MS>
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, const int tiles_per_img) {
     constexpr int BM = 128, WM = 2, WN = 2;
     constexpr int NB = (BN * 8 + 255) / 256;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / MS, TN = WTN / MS;
     constexpr int ACCN = MS == 32 ? 16 : 4;
-    constexpr int PP = APL ? (HALO_ROWS + 63) / 64 : (HALO_ROWS + 31) / 32;   // patch items per thread (plane: 64 rows x 4 chunks per pass)
+    constexpr int PP = (HALO_ROWS + 31) / 32;              // patch rows per thread
     constexpr int PATCH = 2 * HALO_ROWS * ROWB;            // bytes: 2 planes
     constexpr int BSTAGE = 2 * BN * ROWB;                  // bytes per filter stage: 2 planes
     typedef float accv __attribute__((ext_vector_type(ACCN)));
@@ -822,14 +764,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
     int a_lds[PP];
 #pragma unroll
     for (int p = 0; p < PP; ++p) {
-        const int j = APL ? p * 64 + (tid >> 2) : p * 32 + lrow;
-        const int ach = APL ? (tid & 3) : kc;
+        const int j = p * 32 + lrow;
+        const int ach = kc;
         const int pf = p_lo + j;
         const int hp = pf / Wp, wp = pf - hp * Wp;
         const bool ok = j < prow_n && hp >= 1 && hp <= H && wp >= 1 && wp <= W;
         a_off[p] = ok ? (unsigned)((hp - 1) * W + (wp - 1)) * pix_bytes + ach * 16u : OOB;
-        if (APL) a_lds[p] = j < HALO_ROWS ? j * ROWB + ((ach ^ lds_swz<MS>(j)) << 4) : -1;
-        else a_lds[p] = j < HALO_ROWS ? j * ROWB + (((kc >> 1) ^ lds_swz<MS>(j)) << 4) + ((kc & 1) << 3) : -1;
+        a_lds[p] = j < HALO_ROWS ? j * ROWB + (((kc >> 1) ^ lds_swz<MS>(j)) << 4) + ((kc & 1) << 3) : -1;
     }
     // ---- filter chunks of this thread
     unsigned b_off[NB];
@@ -864,22 +805,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_f16x2(const ConvGeom g, c
             }
     };
     auto stage_patch = [&](int cc) {
-        if constexpr (APL) {
-            u32x4 rp[PP][2];
-            const unsigned a_lo = (unsigned)g.Cs * 2u;
-#pragma unroll
-            for (int p = 0; p < PP; ++p) {
-                rp[p][0] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u), 0);
-                rp[p][1] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)a_off[p], (int)((unsigned)cc * 64u + a_lo), 0);
-            }
-#pragma unroll
-            for (int p = 0; p < PP; ++p)
-                if (a_lds[p] >= 0) {
-                    *reinterpret_cast<u32x4*>(smem_b + a_lds[p]) = rp[p][0];
-                    *reinterpret_cast<u32x4*>(smem_b + HALO_ROWS * ROWB + a_lds[p]) = rp[p][1];
-                }
-            return;
-        }
         f32x4 ra[PP];
 #pragma unroll
         for (int p = 0; p < PP; ++p) ra[p] = y4_buf_load4(src_rsrc, a_off[p], (unsigned)cc * 128u);
@@ -1140,7 +1065,7 @@ bool halo_ok(const ConvGeom& g) {
     return halo_patch_rows(g.Hs, g.Ws) <= HALO_ROWS;
 }
 
-template <bool TR, int MS, bool APL = false>
+template <bool TR, int MS>
 int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     constexpr int BN = 128;
     ConvGeom g = g0;
@@ -1151,14 +1076,14 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
     if (nparts) *nparts = g.mtiles;
     const size_t smem = 2ull * HALO_ROWS * ROWB + 2ull * 2 * BN * ROWB;
-    auto kern = conv3x3_halo_f16x2<BN, TR, MS, APL>;
+    auto kern = conv3x3_halo_f16x2<BN, TR, MS>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
-    y4::note_kernel("conv3x3_halo_f16x2<%d, %s, %d, %s>", BN, TR ? "true" : "false", MS, APL ? "true" : "false");
+    y4::note_kernel("conv3x3_halo_f16x2<%d, %s, %d>", BN, TR ? "true" : "false", MS);
     hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(256), smem, st, g, tiles_per_img);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1172,7 +1097,7 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
 // RESB: the launch has a skip operand: its loads are batched ahead of the stores.
 // PLAIN: no scale / shift / activation / BatchNorm statistics (a dgrad launch): 16 fewer live registers, which the
 //        K = N = 128 form with a skip operand needs to stay out of scratch.
-template <int KS, int NT, int NW = 4, bool APL = false, bool RESB = false, bool PLAIN = false>
+template <int KS, int NT, int NW = 4, bool RESB = false, bool PLAIN = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2(const ConvGeom g) {
     constexpr int NTHR = NW * 64, TROWS = NW * 32;
     constexpr int K = KS * 16;
@@ -1202,19 +1127,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
     const float un = f16x2_unscale(g.src_amax) * f16x2_unscale(g.wt_amax);
     const float un1 = un * (1.0f / 2048.0f);
     constexpr int KH = KS == 8 ? 4 : KS;
-    f32x4 ra0[KH][2], ra1[KH][2];                         // APL: [ks][0] = hi fragment, [ks][1] = lo fragment (bit patterns)
+    f32x4 ra0[KH][2], ra1[KH][2];
     auto load = [&](f32x4 (&ra)[KH][2], int tile, int ks0) {
         const int m = tile * TROWS + wave * 32 + fr;
-        if constexpr (APL) {
-            // pre-split source: lane (pixel fr, k half fh) takes 8 consecutive channels = 16 B of each plane
-            const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 16u : 0xffffffffu;
-#pragma unroll
-            for (int ks = 0; ks < KH; ++ks) {
-                ra[ks][0] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 32u);
-                ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 32u + (unsigned)K * 2u);
-            }
-            return;
-        }
         const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 32u : 0xffffffffu;
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
@@ -1246,10 +1161,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
             f16x8 fah, fal;
-            if constexpr (APL) {
-                fah = __builtin_bit_cast(f16x8, ra[ks][0]);
-                fal = __builtin_bit_cast(f16x8, ra[ks][1]);
-            } else {
+            {
                 u32x2 h0, l0, h1, l1;
                 split2x4(ra[ks][0], sa, h0, l0);
                 split2x4(ra[ks][1], sa, h1, l1);
@@ -1365,20 +1277,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
     }
 }
 
-template <int KS, int NT, int NW, bool APL, bool RESB, bool PLAIN = false>
+template <int KS, int NT, int NW, bool RESB, bool PLAIN = false>
 int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts);
 template <int KS, int NT, int NW = 4>
 int launch_stream1x1_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
-    if (g0.src_planes) return launch_stream1x1_f16x2_impl<KS, NT, NW, true, false>(g0, st, nparts);
     if constexpr (KS == 8 && NT == 4) {                    // K = N = 128 with a skip operand: in registers only as PLAIN
         if (g0.res && !g0.scale && !g0.shift && !g0.stats && g0.act == Y4_ACT_LINEAR)
-            return launch_stream1x1_f16x2_impl<KS, NT, NW, false, true, true>(g0, st, nparts);
+            return launch_stream1x1_f16x2_impl<KS, NT, NW, true, true>(g0, st, nparts);
     } else if constexpr (NT <= 2) {                        // (the other NT = 4 forms spill 20-88 registers with the batch)
-        if (g0.res) return launch_stream1x1_f16x2_impl<KS, NT, NW, false, true>(g0, st, nparts);
+        if (g0.res) return launch_stream1x1_f16x2_impl<KS, NT, NW, true>(g0, st, nparts);
     }
-    return launch_stream1x1_f16x2_impl<KS, NT, NW, false, false>(g0, st, nparts);
+    return launch_stream1x1_f16x2_impl<KS, NT, NW, false>(g0, st, nparts);
 }
-template <int KS, int NT, int NW, bool APL, bool RESB, bool PLAIN>
+template <int KS, int NT, int NW, bool RESB, bool PLAIN>
 int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts) {
     ConvGeom g = g0;
     g.mtiles = (g.M + NW * 32 - 1) / (NW * 32);
@@ -1387,7 +1298,7 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     size_t smem = (size_t)2 * NT * 32 * (KS * 32 + 16);
     const size_t red = (size_t)NW * NT * 32 * 2 * sizeof(float);
     if (smem < red) smem = red;
-    auto kern = conv1x1_stream_f16x2<KS, NT, NW, APL, RESB, PLAIN>;
+    auto kern = conv1x1_stream_f16x2<KS, NT, NW, RESB, PLAIN>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1397,8 +1308,7 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     const int resident = NW == 8 ? 256 : 512;             // blocks per CU: 1 (8 waves) or 2
     const int grid = g.mtiles < resident ? g.mtiles : resident;
     if (nparts) *nparts = grid;
-    y4::note_kernel("conv1x1_stream_f16x2<%d, %d, %d, %s, %s, %s>", KS, NT, NW, APL ? "true" : "false", RESB ? "true" : "false",
-                    PLAIN ? "true" : "false");
+    y4::note_kernel("conv1x1_stream_f16x2<%d, %d, %d, %s, %s>", KS, NT, NW, RESB ? "true" : "false", PLAIN ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1544,7 +1454,9 @@ __global__ __launch_bounds__(256) void f16x2_split_filter_folded_kernel(const fl
 __global__ __launch_bounds__(256) void f16x2_transpose_split_filter_folded_kernel(const float* __restrict__ w,
                                                                                   unsigned short* __restrict__ planes, int Cout, int Cin,
                                                                                   int kk, int Cout_pad, const unsigned* __restrict__ part,
-                                                                                  int nparts, unsigned* __restrict__ amax_out) {
+                                                                                  int nparts, unsigned* __restrict__ amax_out, int mirror) {
+    // mirror: tap t is written at position kk - 1 - t, which turns the stride-1 dgrad into a FORWARD-form gather
+    // (source pixel h - pad + r' with r' = k - 1 - r): conv_planes.hip runs dgrad on its forward kernel
     const unsigned amax = amax_fold_partials(part, nparts, amax_out);
     const float s = __uint_as_float(f16x2_scale_exp(amax) << 23);
     const long long total = (long long)Cin * kk * Cout_pad;
@@ -1552,7 +1464,8 @@ __global__ __launch_bounds__(256) void f16x2_transpose_split_filter_folded_kerne
          i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i % Cout_pad);
         const long long t = i / Cout_pad;
-        const int tap = (int)(t % kk);
+        const int tp = (int)(t % kk);
+        const int tap = mirror ? kk - 1 - tp : tp;
         const int c = (int)(t / kk);
         const float v = n < Cout ? w[((long long)n * kk + tap) * Cin + c] : 0.0f;
         unsigned short hi, lo;
@@ -1639,7 +1552,7 @@ __global__ __launch_bounds__(256) void f16x2_split_filter_if_changed_kernel(cons
 
 int g_f16x2_shape = 16;          // MFMA shape of the f16x2 kernels: 32 (32x32x16) or 16 (16x16x32); Y4_F16X2_SHAPE overrides
 
-template <int BM, int BN, int WM, int WN, bool TR, int MS, bool APL = false>
+template <int BM, int BN, int WM, int WN, bool TR, int MS>
 int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
     ConvGeom g = g0;
     if (TR && g.stride == 2) {
@@ -1669,7 +1582,7 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
         g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 2ull * 2ull);
     }
     size_t smem = (size_t)gather_rowm_off<BM, BN, WM, WN, MS>() + BM * sizeof(int);
-    auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS, APL>;
+    auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1686,7 +1599,7 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
         g.cls_slot0[4] = sl;
         grid = sl * 8;
     }
-    y4::note_kernel("conv_gather_f16x2<%d, %d, %d, %d, %s, %d, %s>", BM, BN, WM, WN, TR ? "true" : "false", MS, APL ? "true" : "false");
+    y4::note_kernel("conv_gather_f16x2<%d, %d, %d, %d, %s, %d>", BM, BN, WM, WN, TR ? "true" : "false", MS);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -1695,21 +1608,6 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
 template <bool TR, int MS>
 int dispatch_gather_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
     if (nparts) *nparts = (g.M + 127) / 128;
-    if constexpr (TR) {
-        if (g.src_planes) {                                // dgrad of a BatchNorm layer: dy arrives as planes
-            if (g.Cs_valid != g.Cs) return Y4_ERR_SHAPE;
-            if (g.N > 64) {
-                const long long nt = (g.N + 127) / 128;
-                const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
-                const double c128 = (double)((b128 + 511) / 512) * 128.0;
-                const double c64 = (double)((b64 + 511) / 512) * 64.0 * 1.10;
-                if (c64 < c128 && g.stride != 2) return launch_gather_f16x2<64, 128, 2, 2, TR, MS, true>(g, st);
-                return launch_gather_f16x2<128, 128, 2, 2, TR, MS, true>(g, st);
-            }
-            if (g.N > 32) return launch_gather_f16x2<128, 64, 2, 2, TR, MS, true>(g, st);
-            return launch_gather_f16x2<128, 32, 4, 1, TR, MS, true>(g, st);
-        }
-    }
     if (g.N > 64) {
         const long long nt = (g.N + 127) / 128;
         const long long b128 = ((long long)g.M + 127) / 128 * nt, b64 = ((long long)g.M + 63) / 64 * nt;
@@ -1725,29 +1623,20 @@ int dispatch_gather_f16x2(const ConvGeom& g, hipStream_t st, int* nparts) {
     return launch_gather_f16x2<128, 32, 4, 1, TR, MS>(g, st);
 }
 
-template <int TN_, int TJ_, int MS, bool APL>
-int launch_wgrad_f16x2_impl(const WgradGeom& g, hipStream_t st) {
+template <int TN_, int TJ_, int MS>
+int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
     const size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;
-    auto kern = conv_wgrad_f16x2<TN_, TJ_, MS, APL>;
+    auto kern = conv_wgrad_f16x2<TN_, TJ_, MS>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
         attr_done = true;
     }
-    y4::note_kernel("conv_wgrad_f16x2<%d, %d, %d, %s>", TN_, TJ_, MS, APL ? "true" : "false");
+    y4::note_kernel("conv_wgrad_f16x2<%d, %d, %d>", TN_, TJ_, MS);
     hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
-}
-
-template <int TN_, int TJ_, int MS>
-int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
-    if (g.dy_planes) {
-        if (g.Cout % 32 != 0 || g.lddy != g.Cout) return Y4_ERR_SHAPE;
-        return launch_wgrad_f16x2_impl<TN_, TJ_, MS, true>(g, st);
-    }
-    return launch_wgrad_f16x2_impl<TN_, TJ_, MS, false>(g, st);
 }
 
 int f16x2_shape() {
@@ -1767,10 +1656,6 @@ namespace y4 {
 int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts) {
     if (stream1x1_f16x2_ok(g)) return dispatch_stream1x1_f16x2(g, st, nparts);
     if (halo_ok(g)) {
-        if (transposed && g.src_planes) {
-            if (g.Cs_valid != g.Cs) return Y4_ERR_SHAPE;
-            return f16x2_shape() == 16 ? launch_halo_f16x2<true, 16, true>(g, st, nparts) : launch_halo_f16x2<true, 32, true>(g, st, nparts);
-        }
         if (f16x2_shape() == 16) return transposed ? launch_halo_f16x2<true, 16>(g, st, nparts) : launch_halo_f16x2<false, 16>(g, st, nparts);
         return transposed ? launch_halo_f16x2<true, 32>(g, st, nparts) : launch_halo_f16x2<false, 32>(g, st, nparts);
     }
@@ -1831,14 +1716,14 @@ int f16x2_filter_planes(const float* w, unsigned short* planes, int Cout, int K,
 }
 
 int f16x2_filter_planes_transposed(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
-                                   unsigned* amax_out, unsigned* part, hipStream_t st) {
+                                   unsigned* amax_out, unsigned* part, hipStream_t st, bool mirror) {
     const int np = filter_amax_partials(w, (long long)Cout * kk * Cin, part, st);
     if (np < 0) return Y4_ERR_SHAPE;
     Y4_CHECK_LAUNCH();
     const long long total = (long long)Cin * kk * Cout_pad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipLaunchKernelGGL(f16x2_transpose_split_filter_folded_kernel, dim3(blocks), dim3(256), 0, st, w, planes, Cout, Cin, kk,
-                       Cout_pad, part, np, amax_out);
+                       Cout_pad, part, np, amax_out, mirror ? 1 : 0);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

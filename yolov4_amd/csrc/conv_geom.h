@@ -33,7 +33,6 @@ struct ConvGeom {
     // into [2^14, 2^15) before it is split into fp16 pieces, and the epilogue undoes both scales
     const unsigned* src_amax; const unsigned* wt_amax;
     unsigned* dst_amax;           // f16x2 forward, optional: max|finite output| folded in with atomicMax
-    int src_planes;               // f16x2: the gathered tensor is already split: per pixel [Cs hi halfs][Cs lo halfs] (4 Cs bytes)
 };
 
 struct WgradGeom {
@@ -46,7 +45,6 @@ struct WgradGeom {
     int ntn, ntj, splits, chunks_per_split;   // chunks of 32 pixels
     int tn, tj;     // tile edges chosen by the planner (64 or 128)
     const unsigned* x_amax; const unsigned* dy_amax;   // f16x2 mode, as ConvGeom::src_amax
-    int dy_planes;                // f16x2: dy is already split (as ConvGeom::src_planes)
     unsigned long long x_total_bytes, dy_total_bytes;   // whole tensors; blocks re-base their 32-bit windows
 };
 
@@ -59,11 +57,23 @@ int f16x2_refresh_prepared(const float* w, void* prepared, int Cout, int K, hipS
 // by every block of the split kernel (block 0 leaves the result in *amax_out for the conv kernel's epilogue)
 int f16x2_filter_planes(const float* w, unsigned short* planes, int Cout, int K, unsigned* amax_out, unsigned* part, hipStream_t st);
 int f16x2_filter_planes_transposed(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
-                                   unsigned* amax_out, unsigned* part, hipStream_t st);
+                                   unsigned* amax_out, unsigned* part, hipStream_t st, bool mirror = false);
+// conv_igemm.hip: dw[n] = sum over `splits` fp32 slabs of n elements each, fixed order (deterministic)
+int slab_reduce(const float* slabs, float* dw, long long n, int splits, hipStream_t st);
 int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax_bits, hipStream_t st,
                 bool prezeroed = false);     // zeroes the word first unless the caller hands in a zeroed one
 int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st);
 
+
+// conv_planes.hip: DMA-fed kernels over pre-split operands
+bool planes_conv_ok(int Cin, int Cout, int k, int stride);
+int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,
+                const float* res, long long ldr, float* stats, int* nparts, int B, int Hs, int Ws, int Cs, int N, int k, int stride,
+                hipStream_t st);
+int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st);
+void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps);
+int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const unsigned* dy_amax, float* dw, void* workspace,
+                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st);
 
 // Name of the conv kernel launched last on this host thread, spelled as rocprofv3 prints the symbol (bench.py names the
 // dominant kernel with it instead of restating the dispatch rules).

@@ -1726,6 +1726,25 @@ constexpr int STEM_WAVES = 4096;
 
 }  // namespace
 
+namespace y4 {
+int slab_reduce(const float* slabs, float* dw, long long n, int splits, hipStream_t st) {
+    if ((n & 3) == 0 && !(reinterpret_cast<uintptr_t>(dw) & 15) && !(reinterpret_cast<uintptr_t>(slabs) & 15)) {
+        const long long nvec = n / 4;
+        if (nvec >= 64 * 1024)
+            hipLaunchKernelGGL(slab_reduce_vec_kernel<64>, dim3((unsigned)((nvec + 63) / 64)), dim3(256), 0, st,
+                               reinterpret_cast<const f32x4*>(slabs), reinterpret_cast<f32x4*>(dw), nvec, splits);
+        else
+            hipLaunchKernelGGL(slab_reduce_vec_kernel<16>, dim3((unsigned)((nvec + 15) / 16)), dim3(256), 0, st,
+                               reinterpret_cast<const f32x4*>(slabs), reinterpret_cast<f32x4*>(dw), nvec, splits);
+    } else {
+        const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, slabs, dw, n, splits);
+    }
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+}  // namespace y4
+
 // ======================================================================================== C ABI
 extern "C" {
 
@@ -1863,7 +1882,7 @@ size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k) {
 
 static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx, int lddx,
                            int B, int H, int W, int Cin, int Cout, int k, int stride,
-                           void* workspace, size_t workspace_bytes, const unsigned* dy_amax, int dy_is_planes,
+                           void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                            const float* residual, int ldr, void* stream) {
     if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
@@ -1903,8 +1922,6 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     const long long M = (long long)B * H * W;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = k * k * Cout_pad; g.act = Y4_ACT_LINEAR;
-    if (dy_is_planes && (g_conv_mode != 3 || !dy_amax || Cout_pad != Cout || lddy != Cout)) return Y4_ERR_SHAPE;
-    g.src_planes = dy_is_planes;
     if (g_conv_mode == 3) {
         if (!dy_amax) {
             // pad channels of dy may hold anything: the maximum is taken over the valid channels only
@@ -1920,10 +1937,10 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
 
 int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
-                        void* workspace, size_t workspace_bytes, const unsigned* dy_amax, int dy_is_planes,
+                        void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                         const float* residual, int ldr, void* stream) {
     return conv_dgrad_impl(dy, lddy, w, dx, lddx, B, H, W, Cin, Cout, k, stride, workspace, workspace_bytes, dy_amax,
-                           dy_is_planes, residual, ldr, stream);
+                           residual, ldr, stream);
 }
 
 int y4_last_conv_kernel(char* buf, int cap) {
@@ -1965,7 +1982,7 @@ size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, 
 int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
-                        int dy_is_planes, void* stream) {
+                        void* stream) {
     if (!x || !dy || !dw) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1992,7 +2009,6 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
         g.out = dw;
     }
     int rc;
-    if (dy_is_planes && (g_conv_mode != 3 || !dy_amax)) return Y4_ERR_SHAPE;
     if (g_conv_mode == 3) {
         if (!x_amax || !dy_amax) {
             if (!workspace || workspace_bytes < slab_bytes + 64) return Y4_ERR_WORKSPACE;
@@ -2008,7 +2024,7 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
                 dy_amax = hdr + 1;
             }
         }
-        g.x_amax = x_amax; g.dy_amax = dy_amax; g.dy_planes = dy_is_planes;
+        g.x_amax = x_amax; g.dy_amax = dy_amax;
         rc = y4::f16x2_wgrad(g, st);
     } else if (g_conv_mode == 1) {
         if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, 3>(g, st);
@@ -2026,21 +2042,8 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
     else rc = launch_wgrad<64, 64>(g, st);
     if (rc != Y4_OK) return rc;
     if (g.splits > 1) {
-        const long long n = (long long)Cout * g.J;
-        if ((n & 3) == 0 && !(reinterpret_cast<uintptr_t>(dw) & 15) && !(reinterpret_cast<uintptr_t>(workspace) & 15)) {
-            const long long nvec = n / 4;
-            if (nvec >= 64 * 1024)
-                hipLaunchKernelGGL(slab_reduce_vec_kernel<64>, dim3((unsigned)((nvec + 63) / 64)), dim3(256), 0, st,
-                                   static_cast<const f32x4*>(workspace), reinterpret_cast<f32x4*>(dw), nvec, g.splits);
-            else
-                hipLaunchKernelGGL(slab_reduce_vec_kernel<16>, dim3((unsigned)((nvec + 15) / 16)), dim3(256), 0, st,
-                                   static_cast<const f32x4*>(workspace), reinterpret_cast<f32x4*>(dw), nvec, g.splits);
-        } else {
-            const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st,
-                               static_cast<const float*>(workspace), dw, n, g.splits);
-        }
-        Y4_CHECK_LAUNCH();
+        const int rc2 = y4::slab_reduce(static_cast<const float*>(workspace), dw, (long long)Cout * g.J, g.splits, st);
+        if (rc2 != Y4_OK) return rc2;
     }
     return Y4_OK;
 }

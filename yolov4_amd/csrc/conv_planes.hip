@@ -1,0 +1,754 @@
+// Implicit-GEMM convolution over PRE-SPLIT operands ("planes"), gfx950 only: LDS-DMA + ds_read_b128 + MFMA, no VALU in
+// the K loop.
+//
+// Arithmetic: the f16x2 split of conv_f16x2.hip (every operand tensor scaled by a power of two from an upper bound of
+// its max|x|, each element two fp16 pieces hi = RN16(s x), lo = RN16((s x - hi) 2^11); three fp16 MFMAs per product into
+// two fp32 accumulators; c = (acc0 + 2^-11 acc1) / (s_A s_B)).  What changes is WHO splits: here both operands arrive
+// in HBM already split -- activations / gradients written that way by the BatchNorm sweeps that produce them
+// (pointwise.hip, `planes` outputs), filters by the per-call split kernels -- in the layout the DMA wants:
+//
+//     tensor[pixel or filter row][K-tile of 32 channels][ 64 B: 32 hi halfs | 64 B: 32 lo halfs ]
+//
+// i.e. 4 bytes per element like fp32, one K-tile of one row = one whole 128-B line.  A block stages a K-tile of BM
+// activation rows and BN filter rows with `buffer_load_dwordx4 ... lds` (16 B per lane, 8 lanes per row: a wave
+// instruction moves 8 whole lines; per-lane SOURCE addresses make it a gather over the filter taps, the descriptor's
+// range check turns halo / tail rows into zeros), into a lane-linear LDS image whose 16-B chunks are XOR-swizzled on the
+// source address (chunk c of row r sits at position c ^ ((r >> 1) & 7): every ds_read_b128 lane group of the 16x16x32
+// fragment reads is conflict-free).  Three LDS stages, two K-tiles of DMA in flight across ONE raw s_barrier per K-tile
+// with a counted vmcnt, one 8-wave 256 x 128 block per CU (wave tile 64 x 64: 48 MFMAs + 16 ds_read_b128 + 6 DMA issues
+// per wave and K-tile).
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "conv_geom.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __host__ __forceinline__ unsigned pl_scale_exp(unsigned amax_bits) {      // as f16x2_scale_exp (conv_f16x2.hip)
+    const unsigned e = (amax_bits >> 23) & 0xffu;
+    if (e == 0u || e == 255u) return 127u;
+    int se = 268 - (int)e;
+    if (se < 2) se = 2;
+    if (se > 252) se = 252;
+    return (unsigned)se;
+}
+__device__ __forceinline__ float pl_scale(const unsigned* amax) { return __uint_as_float(pl_scale_exp(amax ? *amax : 0u) << 23); }
+__device__ __forceinline__ float pl_unscale(const unsigned* amax) { return __uint_as_float((254u - pl_scale_exp(amax ? *amax : 0u)) << 23); }
+
+struct PlaneConvGeom {
+    const unsigned char* src;          // activation planes [B][Hs][Ws][Cs / 32][128 B]
+    const unsigned char* wt;           // filter planes [N][K / 32][128 B], K order (tap, channel)
+    float* dst; long long ldd;         // raw fp32 result [M][ldd]
+    const float* res; long long ldr;   // optional: added in the epilogue (dgrad: gradient arriving over a skip connection)
+    float* stats;                      // optional: per-M-tile column sums [mtiles][2][N] of the result
+    int B, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad, M, K;
+    int mtiles, ntiles;
+    unsigned long long src_total_bytes;
+    unsigned wt_bytes;
+    const unsigned* src_amax; const unsigned* wt_amax;
+};
+
+constexpr int PROW = 128;                                  // bytes per LDS row: one 32-deep K-tile, [64 B hi | 64 B lo]
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g) {
+    constexpr int NWAVE = 8;
+    static_assert(WM * WN == NWAVE, "8 waves");
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
+    constexpr int A_BYTES = BM * PROW, B_BYTES = BN * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    constexpr int PA = BM / 8 / NWAVE, PB = BN / 8 / NWAVE, NDMA = PA + PB;      // 1-KiB DMA pieces per wave and K-tile
+    static_assert(PA >= 1 && PB >= 1 && NDMA == 6, "the counted vmcnt below assumes 6 pieces per wave and K-tile");
+    typedef float accv __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lt = y4_xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
+    const int mt = lt / g.ntiles, nt = lt - mt * g.ntiles;
+    const int n0 = nt * BN;
+    const int CC = g.Cs >> 5;
+    const int KT = g.k * g.k * CC;
+
+    // ---- 32-bit window of the source tensor, re-based at the first image this tile touches
+    const int pix_per_img = g.Hd * g.Wd;
+    const int b_first = (int)(((long long)mt * BM) / pix_per_img);
+    const unsigned pitch = (unsigned)g.Cs * 4u;
+    const unsigned long long img_bytes = (unsigned long long)g.Hs * g.Ws * pitch;
+    const unsigned long long skip = (unsigned long long)b_first * img_bytes;
+    const unsigned long long left = g.src_total_bytes > skip ? g.src_total_bytes - skip : 0ull;
+    const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src + skip, (unsigned)(left < 0xfffffff0ull ? left : 0xfffffff0ull));
+    const __amdgpu_buffer_rsrc_t wt_rsrc = y4_make_rsrc(g.wt, g.wt_bytes);
+    const unsigned OOB = 0xffffffffu;                      // beyond any window: the range check returns zeros (halo, tail rows)
+
+    // ---- DMA slots of this lane: 8 lanes per row, lane -> (row of the piece, position in the row)
+    const int lr = lane >> 3, pos = lane & 7;
+    unsigned a_base[PA], a_valid[PA], a_voff[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wave * PA + i) * 8 + lr;
+        const int m = mt * BM + row;
+        const bool ok = m < g.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / pix_per_img;
+        const int rem = mm - b * pix_per_img;
+        const int hd = rem / g.Wd, wd = rem - hd * g.Wd;
+        const int hc = hd * g.stride - g.pad, wc = wd * g.stride - g.pad;
+        const int chunk = pos ^ ((row >> 1) & 7);
+        a_base[i] = (unsigned)(((b - b_first) * g.Hs + hc) * g.Ws + wc) * pitch + (unsigned)chunk * 16u;   // mod 2^32
+        unsigned v = 0u;
+        for (int r = 0; r < g.k; ++r)
+            for (int q = 0; q < g.k; ++q)
+                if (ok && (unsigned)(hc + r) < (unsigned)g.Hs && (unsigned)(wc + q) < (unsigned)g.Ws) v |= 1u << (r * g.k + q);
+        a_valid[i] = v;
+    }
+    unsigned b_off[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int row = (wave * PB + j) * 8 + lr;
+        const int chunk = pos ^ ((row >> 1) & 7);
+        b_off[j] = (n0 + row) < g.N ? (unsigned)(n0 + row) * (unsigned)g.K * 4u + (unsigned)chunk * 16u : OOB;
+    }
+    // ---- DMA issue state: the K-tile (ld_tap, ld_cc) whose pieces are going out next; taps outer, channel chunks inner
+    int ld_tap = 0, ld_r = 0, ld_q = 0, ld_cc = 0;
+    auto tap_setup = [&]() {
+        const unsigned toff = (unsigned)(ld_r * g.Ws + ld_q) * pitch;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) a_voff[i] = ((a_valid[i] >> ld_tap) & 1u) ? a_base[i] + toff : OOB;
+    };
+    tap_setup();
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    // pieces [p0, p1) of the current K-tile into stage `stage` (pieces 0..PA-1: activation rows, PA..NDMA-1: filter rows)
+    auto issue = [&](int stage, auto P0, auto P1) {
+        constexpr int p0 = decltype(P0)::value, p1 = decltype(P1)::value;
+        unsigned char* st = smem + stage * STAGE;
+        const unsigned soff_a = (unsigned)ld_cc * 128u;
+        const unsigned soff_b = (unsigned)(ld_tap * CC + ld_cc) * 128u;
+#pragma unroll
+        for (int p = p0; p < p1; ++p) {
+            if (p < PA)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(st + (wave * PA + p) * 1024), 16, (int)a_voff[p], (int)soff_a, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wt_rsrc, (lds_ptr)(st + A_BYTES + (wave * PB + (p - PA)) * 1024), 16,
+                                                         (int)b_off[p - PA], (int)soff_b, 0, 0);
+        }
+        if constexpr (p1 == NDMA) {                        // K-tile complete: advance
+            if (++ld_cc == CC) {
+                ld_cc = 0; ++ld_tap;
+                if (++ld_q == g.k) { ld_q = 0; ++ld_r; }
+                tap_setup();
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    using I6 = std::integral_constant<int, NDMA>;
+
+    accv acc0[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+
+    // ---- fragment addresses: lane -> (row fr of a 16-row tile, K quarter kq); logical chunks kq (hi) and 4 + kq (lo)
+    const int fr = lane & 15, kq = lane >> 4;
+    const int sw = (fr >> 1) & 7;                          // tile bases are multiples of 16 rows: the swizzle depends on fr only
+    const int a_hi = (wm * WTM + fr) * PROW + ((kq ^ sw) << 4), a_lo = (wm * WTM + fr) * PROW + (((4 + kq) ^ sw) << 4);
+    const int b_hi = A_BYTES + (wn * WTN + fr) * PROW + ((kq ^ sw) << 4), b_lo = A_BYTES + (wn * WTN + fr) * PROW + (((4 + kq) ^ sw) << 4);
+
+    // ---- K loop.  Three stages, ring position = K-tile index mod 3 (compile time: the loop is unrolled by 3).  Step t:
+    //   fragments of tile t -> MFMAs of the first TM - 1 row tiles, the DMA pieces of a tile under way spread between them;
+    //   then [own reads returned | own pieces of tile t + 1 landed: counted vmcnt | barrier]: tile t + 1 is readable and
+    //   stage t mod 3 is free for EVERY wave -> the first pieces of tile t + 3 go out; last row tile's MFMAs.
+    // The barrier sits in front of the last MFMA group, so the next step's first fragment reads (after it in program
+    // order) are hoisted under those MFMAs by the compiler: no wave starts a step with an empty matrix pipe.
+    bool pend = false;                                     // a K-tile's pieces are partly issued
+    auto step = [&](auto SC, const int kt) {
+        constexpr int S = decltype(SC)::value;
+        const unsigned char* base = smem + S * STAGE;
+        f16x8 fb[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            fb[j][0] = *reinterpret_cast<const f16x8*>(base + b_hi + j * 16 * PROW);
+            fb[j][1] = *reinterpret_cast<const f16x8*>(base + b_lo + j * 16 * PROW);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f16x8 fa0 = *reinterpret_cast<const f16x8*>(base + a_hi + i * 16 * PROW);
+            const f16x8 fa1 = *reinterpret_cast<const f16x8*>(base + a_lo + i * 16 * PROW);
+            if (i == TM - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of stage S has returned
+                if (kt + 1 < KT) {
+                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (kt + 3 < KT) { issue(S, I0{}, I2{}); pend = true; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[j][0], acc1[i][j], 0, 0, 0);
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
+                acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
+            }
+            if (i == 0 && pend) issue((S + 2) % NSTAGE, I2{}, I4{});
+            if (i == 1 && pend) { issue((S + 2) % NSTAGE, I4{}, I6{}); pend = false; }
+        }
+    };
+    static_assert(TM >= 3, "the DMA pieces are spread over the first three row tiles");
+
+    for (int t = 0; t < 3 && t < KT; ++t) issue(t, I0{}, I6{});
+    if (KT >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (KT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        int kt = 0;
+        for (; kt + 3 <= KT; kt += 3) {
+            step(std::integral_constant<int, 0>{}, kt);
+            step(std::integral_constant<int, 1>{}, kt + 1);
+            step(std::integral_constant<int, 2>{}, kt + 2);
+        }
+        if (kt < KT) step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < KT) step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    // ---- epilogue: c = (acc0 + 2^-11 acc1) / (s_A s_B); 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + e.
+    // Every wave passes its 64 x 64 sub-tile through its own LDS patch ([row][WTN + 4] floats) and writes float4 rows:
+    // a wave instruction stores 4 rows x 256 contiguous bytes.
+    const float un = pl_unscale(g.src_amax) * pl_unscale(g.wt_amax);
+    const float un1 = un * (1.0f / 2048.0f);
+    __syncthreads();                                       // every wave has left the last stage
+    constexpr int EP = WTN + 4;
+    static_assert(NWAVE * WTM * EP * 4 + WM * BN * 2 * 4 <= NSTAGE * STAGE, "epilogue patches + column sums must fit the stages");
+    float* patch = reinterpret_cast<float*>(smem) + wave * (WTM * EP);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                acc0[i][j][e] = v;                         // kept for the column sums
+                patch[(i * 16 + 4 * kq + e) * EP + j * 16 + fr] = v;
+            }
+    // (wave-local: the writes above are ordered before the reads below by the wave's own lgkmcnt wait)
+    constexpr int LPR = WTN / 4, RPI = 64 / LPR;           // lanes per patch row, rows per wave instruction
+    const int c4 = (lane % LPR) * 4;
+    const int nv = n0 + wn * WTN + c4;
+    const bool nok4 = nv < g.N;                            // N % 4 == 0 (host)
+    const long long mrow0 = (long long)mt * BM + wm * WTM;
+#pragma unroll
+    for (int it = 0; it < WTM / RPI; it += 4) {
+        f32x4v rr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long m = mrow0 + (it + u) * RPI + lane / LPR;
+            rr[u] = (g.res && nok4 && m < g.M) ? *reinterpret_cast<const f32x4v*>(g.res + m * g.ldr + nv) : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = (it + u) * RPI + lane / LPR;
+            const long long m = mrow0 + row;
+            f32x4v v = *reinterpret_cast<const f32x4v*>(patch + row * EP + c4);
+            v += rr[u];
+            if (nok4 && m < g.M) *reinterpret_cast<f32x4v*>(g.dst + m * g.ldd + nv) = v;
+        }
+    }
+    if (g.stats) {                                         // rows past M are exact zeros (their operand rows were zero-filled)
+        float* red = reinterpret_cast<float*>(smem + NWAVE * WTM * EP * 4);       // [WM][BN][2], behind the patches
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = acc0[i][j][e]; cs += v; css += v * v; }
+            cs += __shfl_xor(cs, 16, 64); css += __shfl_xor(css, 16, 64);
+            cs += __shfl_xor(cs, 32, 64); css += __shfl_xor(css, 32, 64);
+            if (kq == 0) {
+                const int c = wn * WTN + j * 16 + fr;
+                red[(wm * BN + c) * 2 + 0] = cs;
+                red[(wm * BN + c) * 2 + 1] = css;
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < BN; c += 512) {
+            float cs = 0.f, css = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
+            const int n = n0 + c;
+            if (n < g.N) {
+                g.stats[((long long)mt * 2 + 0) * g.N + n] = cs;
+                g.stats[((long long)mt * 2 + 1) * g.N + n] = css;
+            }
+        }
+    }
+}
+
+// ==================================================================================== wgrad over planes
+// dW[n][j] = sum_p dy[p][n] * x[p @ tap(j)][c(j)], j = (tap, c): a GEMM whose K dimension is the pixel index, i.e. both
+// operands are needed with the CONTRACTION index along the MFMA k axis although they sit in HBM pixel-major.  The LDS
+// image keeps them pixel-major as the DMA delivers them -- one row per (32-channel chunk, pixel), rows of 128 B
+// [hi | lo] -- and the fragments come out of it through `ds_read_b64_tr_b16`, the hardware transpose read: a 16-lane
+// group reads a block of 4 pixel rows x 16 channels and each lane receives ONE channel's 4 consecutive pixels, which is
+// exactly half of an 8-deep k fragment; two such reads per plane and tile, no VALU, no register transposes.
+//   * K-step = 32 consecutive pixels (raster order over batch x H x W); split-K over pixel ranges into fp32 slabs.
+//   * block tile 128 (n) x 256 (j = 8 chunks of 32 channels, each chunk with its own filter tap), 8 waves as 2 x 4,
+//     wave tile 64 x 64, 48 MFMAs per wave and K-step; the same three-stage DMA ring as the forward kernel.
+//   * swizzle: the four 32-B segments of a row ([hi 0-15 | hi 16-31 | lo 0-15 | lo 16-31]) are permuted by
+//     g(p) = ((p >> 1) & 1) | (((p >> 3) & 1) << 1) (XOR on the segment index), which makes every transposed read
+//     conflict-free (a 32-lane half reads pixels {0-3, 8-11} or {4-7, 12-15} of one segment: 8 distinct 32-B slots).
+//   * stride 1 only (the layers this serves): pixel p of dy is pixel p of x, so a lane's x address is linear in p and a
+//     tap is a constant offset plus a validity test on (h, w).
+struct PlaneWgradGeom {
+    const unsigned char* x;            // planes [B][H][W][Cin / 32][128 B]
+    const unsigned char* dy;           // planes [B][H][W][Cout / 32][128 B]
+    float* out;                        // [splits][Cout][J] slabs, or dW itself when splits == 1
+    int B, H, W, Cin, Cout, k, pad, M, J;
+    int ntn, ntj, splits, steps_per_split;
+    unsigned long long x_total_bytes, dy_total_bytes;
+    const unsigned* x_amax; const unsigned* dy_amax;
+};
+
+typedef __fp16 trh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char* p) {      // k 0..3 from p, k 4..7 four pixel rows further
+    typedef __attribute__((address_space(3))) trh4* lp;
+    const trh4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p));
+    const trh4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p + 4 * PROW));
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = (_Float16)a[e]; r[4 + e] = (_Float16)b[e]; }
+    return r;
+}
+
+template <int TN_, int TJ_>
+__global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom g) {
+    constexpr int NWAVE = 8, WN2 = 2, WJ = 4;
+    constexpr int WTN = TN_ / WN2, WTJ = TJ_ / WJ, TM = WTN / 16, TN = WTJ / 16;
+    static_assert(TM == 4 && TN == 4, "wave tile 64 x 64");
+    constexpr int A_BYTES = (TN_ / 32) * 32 * PROW, B_BYTES = (TJ_ / 32) * 32 * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    constexpr int PA = A_BYTES / 1024 / NWAVE, PB = B_BYTES / 1024 / NWAVE, NDMA = PA + PB;
+    static_assert(PA == 2 && PB == 4 && NDMA == 6, "6 DMA pieces per wave and K-step");
+    typedef float accv __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn2 = wave >> 2, wj = wave & 3;
+    const int tiles = g.ntn * g.ntj;
+    int bid = y4_xcd_remap(blockIdx.x, tiles * g.splits);
+    const int split = bid / tiles;
+    bid -= split * tiles;
+    const int tn = bid / g.ntj, tj = bid - tn * g.ntj;
+    const int n0 = tn * TN_, j0 = tj * TJ_;
+    const int CC = g.Cin >> 5;
+
+    const int steps_total = (g.M + 31) >> 5;
+    const int s0 = split * g.steps_per_split;
+    int KT = steps_total - s0;
+    if (KT > g.steps_per_split) KT = g.steps_per_split;
+    if (KT < 0) KT = 0;
+    const long long P0 = (long long)s0 * 32;               // first pixel of this split
+
+    // ---- 32-bit windows: dy from pixel P0; x from pixel P0 - (pad W + pad) (the earliest pixel a tap can reach), >= 0
+    const unsigned pitch_x = (unsigned)g.Cin * 4u, pitch_dy = (unsigned)g.Cout * 4u;
+    const long long back = (long long)g.pad * g.W + g.pad;
+    const long long Pw = P0 > back ? P0 - back : 0;
+    const unsigned long long dy_skip = (unsigned long long)P0 * pitch_dy, x_skip = (unsigned long long)Pw * pitch_x;
+    const unsigned long long dy_left = g.dy_total_bytes > dy_skip ? g.dy_total_bytes - dy_skip : 0ull;
+    const unsigned long long x_left = g.x_total_bytes > x_skip ? g.x_total_bytes - x_skip : 0ull;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = y4_make_rsrc(g.dy + dy_skip, (unsigned)(dy_left < 0xfffffff0ull ? dy_left : 0xfffffff0ull));
+    const __amdgpu_buffer_rsrc_t x_rsrc = y4_make_rsrc(g.x + x_skip, (unsigned)(x_left < 0xfffffff0ull ? x_left : 0xfffffff0ull));
+    const unsigned OOB = 0xffffffffu;
+
+    // ---- DMA slots: 8 lanes per row; lane -> (pixel inside its octet, 16-B position in the row)
+    const int lr = lane >> 3, pos = lane & 7;
+    // dy pieces a = wave * 2 + i: channel chunk a >> 2, pixel octet a & 3
+    unsigned a_voff[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int a = wave * PA + i;
+        const int chunk = a >> 2, p = (a & 3) * 8 + lr;
+        const int gsw = ((p >> 1) & 1) | (((p >> 3) & 1) << 1);
+        const unsigned srcoff = (unsigned)((((pos >> 1) ^ gsw) << 5) + ((pos & 1) << 4));
+        a_voff[i] = (n0 + chunk * 32) < g.Cout ? (unsigned)p * pitch_dy + (unsigned)(n0 / 32 + chunk) * 128u + srcoff : OOB;
+    }
+    // x pieces: pixel octet wave & 3, j chunks (wave >> 2) * 4 + i: ONE pixel per lane, four taps / channel chunks
+    const int xp = (wave & 3) * 8 + lr;                    // pixel of this lane inside the K-step
+    unsigned x_const[PB];                                  // tap offset + channel chunk + swizzled position; OOB: chunk beyond J
+    int x_dh[PB], x_dw[PB];
+    {
+        const int gsw = ((xp >> 1) & 1) | (((xp >> 3) & 1) << 1);
+        const unsigned srcoff = (unsigned)((((pos >> 1) ^ gsw) << 5) + ((pos & 1) << 4));
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int jg = j0 / 32 + (wave >> 2) * PB + i;
+            const bool ok = jg * 32 < g.J;
+            const int tap = ok ? jg / CC : 0;
+            const int c32 = jg - tap * CC;
+            const int r = tap / g.k, q = tap - r * g.k;
+            x_dh[i] = ok ? r - g.pad : (1 << 20);          // (an impossible row: never valid)
+            x_dw[i] = q - g.pad;
+            x_const[i] = (unsigned)((long long)(P0 - Pw) * pitch_x) + (unsigned)(((r - g.pad) * g.W + (q - g.pad)) * (int)pitch_x) +
+                         (unsigned)c32 * 128u + srcoff;
+        }
+    }
+    // running raster position of this lane's pixel of the NEXT K-step to be issued
+    long long lp = P0 + xp;
+    int lh, lw;
+    {
+        const long long hw = (long long)g.H * g.W;
+        const long long rem = lp % hw;
+        lh = (int)(rem / g.W); lw = (int)(rem - (long long)lh * g.W);
+    }
+    unsigned lbase = (unsigned)xp * pitch_x;               // (pixel - P0) * pitch, mod 2^32
+    unsigned ldy = 0u;                                     // K-step offset of the dy rows
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto issue = [&](int stage, auto P0c, auto P1c) {
+        constexpr int p0 = decltype(P0c)::value, p1 = decltype(P1c)::value;
+        unsigned char* st = smem + stage * STAGE;
+#pragma unroll
+        for (int p = p0; p < p1; ++p) {
+            if (p < PA) {
+                const unsigned vo = a_voff[p] == OOB ? OOB : a_voff[p] + ldy;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (lds_ptr)(st + (wave * PA + p) * 1024), 16, (int)vo, 0, 0, 0);
+            } else {
+                const int i = p - PA;
+                const bool ok = lp < g.M && (unsigned)(lh + x_dh[i]) < (unsigned)g.H && (unsigned)(lw + x_dw[i]) < (unsigned)g.W;
+                const unsigned vo = ok ? lbase + x_const[i] : OOB;
+                const int b = ((wave >> 2) * PB + i) * 4 + (wave & 3);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(st + A_BYTES + b * 1024), 16, (int)vo, 0, 0, 0);
+            }
+        }
+        if constexpr (p1 == NDMA) {                        // K-step complete: advance by 32 pixels
+            lp += 32; lbase += 32u * pitch_x; ldy += 32u * pitch_dy;
+            lw += 32;
+            while (lw >= g.W) { lw -= g.W; if (++lh == g.H) lh = 0; }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    using I6 = std::integral_constant<int, NDMA>;
+
+    accv acc0[TM][TN], acc1[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+
+    // ---- transposed fragment reads: lane -> (k group grp: pixels 8 grp + {0..3} and + 4, block row qrow, 8-B piece pp)
+    const int grp = lane >> 4, qrow = (lane >> 2) & 3, pp = lane & 3;
+    const int gsw = ((qrow >> 1) & 1) | ((grp & 1) << 1);
+    const int rowoff = (8 * grp + qrow) * PROW + pp * 8;
+    // logical segment s = plane * 2 + (tile & 1) lives at position s ^ gsw
+    int segoff[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) segoff[s4] = rowoff + ((s4 ^ gsw) << 5);
+    const int a_tile0 = (wn2 * (WTN / 32)) * 32 * PROW;                // chunk of this wave's first n tile
+    const int b_tile0 = A_BYTES + (wj * (WTJ / 32)) * 32 * PROW;
+
+    bool pend = false;
+    auto step = [&](auto SC, const int kt) {
+        constexpr int S = decltype(SC)::value;
+        const unsigned char* base = smem + S * STAGE;
+        f16x8 fb[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            fb[j][0] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[0 + (j & 1)]);
+            fb[j][1] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[2 + (j & 1)]);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f16x8 fa0 = tr_frag(base + a_tile0 + (i >> 1) * 32 * PROW + segoff[0 + (i & 1)]);
+            const f16x8 fa1 = tr_frag(base + a_tile0 + (i >> 1) * 32 * PROW + segoff[2 + (i & 1)]);
+            if (i == TM - 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kt + 1 < KT) {
+                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (kt + 3 < KT) { issue(S, I0{}, I2{}); pend = true; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[j][0], acc1[i][j], 0, 0, 0);
+                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
+                acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
+            }
+            if (i == 0 && pend) issue((S + 2) % NSTAGE, I2{}, I4{});
+            if (i == 1 && pend) { issue((S + 2) % NSTAGE, I4{}, I6{}); pend = false; }
+        }
+    };
+
+    for (int t = 0; t < 3 && t < KT; ++t) issue(t, I0{}, I6{});
+    if (KT >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (KT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        int kt = 0;
+        for (; kt + 3 <= KT; kt += 3) {
+            step(std::integral_constant<int, 0>{}, kt);
+            step(std::integral_constant<int, 1>{}, kt + 1);
+            step(std::integral_constant<int, 2>{}, kt + 2);
+        }
+        if (kt < KT) step(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < KT) step(std::integral_constant<int, 1>{}, kt + 1);
+    }
+
+    // ---- epilogue: out[n][j] = (acc0 + 2^-11 acc1) / (s_dy s_x), through per-wave LDS patches as float4 rows of j
+    const float un = pl_unscale(g.dy_amax) * pl_unscale(g.x_amax);
+    const float un1 = un * (1.0f / 2048.0f);
+    __syncthreads();
+    constexpr int EP = WTJ + 4;
+    static_assert(NWAVE * WTN * EP * 4 <= NSTAGE * STAGE, "epilogue patches must fit the stages");
+    float* patch = reinterpret_cast<float*>(smem) + wave * (WTN * EP);
+    const int fr = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) patch[(i * 16 + 4 * kq + e) * EP + j * 16 + fr] = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+    float* out = g.out + (long long)split * g.Cout * g.J;
+    const int c4 = (lane & 15) * 4;
+    const int jv = j0 + wj * WTJ + c4;
+#pragma unroll
+    for (int it = 0; it < WTN / 4; ++it) {
+        const int row = it * 4 + (lane >> 4);
+        const int n = n0 + wn2 * WTN + row;
+        if (n < g.Cout && jv < g.J)
+            *reinterpret_cast<f32x4v*>(out + (long long)n * g.J + jv) = *reinterpret_cast<const f32x4v*>(patch + row * EP + c4);
+    }
+}
+
+// ---- fp32 NHWC (pitch ld) -> planes; one thread per 4 channels of a pixel
+__global__ __launch_bounds__(256) void planes_split_kernel(const float* __restrict__ x, long long ld, long long M, int C,
+                                                           const unsigned* __restrict__ amax, unsigned char* __restrict__ planes) {
+    const float s = pl_scale(amax);
+    const int C4 = C >> 2;
+    const long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C4;
+        const int c = (int)(i - m * C4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ld + c);
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = v[e] * s;
+            hi[e] = (_Float16)t;
+            lo[e] = (_Float16)((t - (float)hi[e]) * 2048.f);
+        }
+        unsigned char* row = planes + m * (long long)C * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<h4*>(row) = hi;
+        *reinterpret_cast<h4*>(row + 64) = lo;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
+    PlaneConvGeom g = g0;
+    g.mtiles = (g.M + BM - 1) / BM;
+    g.ntiles = (g.N + BN - 1) / BN;
+    constexpr size_t smem = 3ull * (BM + BN) * PROW;
+    auto kern = conv_planes_mfma<BM, BN, WM, WN>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d>", BM, BN, WM, WN);
+    hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(512), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+}  // namespace
+
+namespace y4 {
+
+bool planes_conv_ok(int Cin, int Cout, int k, int stride) {
+    return Cin > 0 && (Cin & 31) == 0 && Cout > 0 && (Cout & 3) == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2);
+}
+
+// forward-form conv over planes: src [B][Hs][Ws][Cs] planes, filter planes [N][k*k*Cs], raw fp32 result (+ res) and
+// optional per-M-tile column sums (256-row tiles)
+int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,
+                const float* res, long long ldr, float* stats, int* nparts, int B, int Hs, int Ws, int Cs, int N, int k, int stride,
+                hipStream_t st) {
+    PlaneConvGeom g{};
+    const int pad = (k - 1) / 2;
+    g.src = static_cast<const unsigned char*>(src); g.wt = static_cast<const unsigned char*>(wt_planes);
+    g.dst = dst; g.ldd = ldd; g.res = res; g.ldr = ldr; g.stats = stats;
+    g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.N = N; g.k = k; g.stride = stride; g.pad = pad;
+    g.Hd = (Hs + 2 * pad - k) / stride + 1;
+    g.Wd = (Ws + 2 * pad - k) / stride + 1;
+    const long long M = (long long)B * g.Hd * g.Wd;
+    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
+    g.M = (int)M; g.K = k * k * Cs;
+    const unsigned long long img = (unsigned long long)Hs * Ws * (unsigned long long)Cs * 4ull;
+    const unsigned long long wb = (unsigned long long)N * g.K * 4ull;
+    // a 256-row tile may span several images: the 32-bit window starts at the first one
+    const unsigned long long imgs_per_tile = 256ull / (unsigned long long)(g.Hd * g.Wd > 0 ? g.Hd * g.Wd : 1) + 2;
+    if (img * imgs_per_tile >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+    g.src_total_bytes = (unsigned long long)B * img;
+    g.wt_bytes = (unsigned)wb;
+    g.src_amax = src_amax; g.wt_amax = wt_amax;
+    if (nparts) *nparts = (g.M + 255) / 256;
+    return launch_conv_planes<256, 128, 4, 2>(g, st);
+}
+
+// split-K plan of the plane wgrad: tiles x splits blocks on 256 CUs (one block per CU), minimising rounds x K-steps per block
+void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps) {
+    const long long M = (long long)B * H * W;
+    const int J = k * k * Cin;
+    *ntn = (Cout + 127) / 128;
+    *ntj = (J + 255) / 256;
+    const int tiles = *ntn * *ntj;
+    const long long steps = (M + 31) / 32;
+    long long best = -1; int bs = 1;
+    for (int s = 1; s <= 256; ++s) {
+        const long long per = (steps + s - 1) / s;
+        if (s > 1 && per < 12) break;
+        const long long rounds = ((long long)tiles * s + 255) / 256;
+        const long long cost = rounds * (per + 6);         // + prologue / epilogue of a block, in K-steps
+        if (best < 0 || cost < best) { best = cost; bs = s; }
+    }
+    const long long per = (steps + bs - 1) / bs;
+    *sps = (int)per;
+    *splits = (int)((steps + per - 1) / per);
+}
+
+int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const unsigned* dy_amax, float* dw, void* workspace,
+                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st) {
+    PlaneWgradGeom g{};
+    g.x = static_cast<const unsigned char*>(x); g.dy = static_cast<const unsigned char*>(dy);
+    g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.pad = (k - 1) / 2;
+    const long long M = (long long)B * H * W;
+    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
+    g.M = (int)M; g.J = k * k * Cin;
+    planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split);
+    g.x_total_bytes = (unsigned long long)M * Cin * 4ull;
+    g.dy_total_bytes = (unsigned long long)M * Cout * 4ull;
+    // a block's 32-bit windows: its K range + the taps' reach
+    const unsigned long long range_px = (unsigned long long)g.steps_per_split * 32ull + 2ull * (unsigned long long)(g.pad * W + g.pad) + 64ull;
+    if (range_px * (unsigned long long)(Cin > Cout ? Cin : Cout) * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+    g.x_amax = x_amax; g.dy_amax = dy_amax;
+    const size_t slab = (size_t)Cout * g.J * sizeof(float);
+    if (g.splits > 1) {
+        if (!workspace || workspace_bytes < slab * g.splits) return Y4_ERR_WORKSPACE;
+        g.out = static_cast<float*>(workspace);
+    } else {
+        g.out = dw;
+    }
+    constexpr size_t smem = 3ull * (128 / 32 + 256 / 32) * 32 * PROW;
+    auto kern = wgrad_planes_mfma<128, 256>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return Y4_ERR_LAUNCH;
+        attr_done = true;
+    }
+    y4::note_kernel("wgrad_planes_mfma<128, 256>");
+    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(512), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    if (g.splits > 1) return y4::slab_reduce(static_cast<const float*>(workspace), dw, (long long)Cout * g.J, g.splits, st);
+    return Y4_OK;
+}
+
+int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st) {
+    const long long total = M * (C / 4);
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(planes_split_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C, amax,
+                       static_cast<unsigned char*>(planes));
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+}  // namespace y4
+
+// ======================================================================================== C ABI
+extern "C" {
+
+int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, void* stream) {
+    if (!x || !amax || !planes) return Y4_ERR_NULL;
+    if (M <= 0 || C <= 0 || (C & 31) || ldx < C || (ldx & 3)) return Y4_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return Y4_ERR_SHAPE;
+    return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream));
+}
+
+int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,
+                             int B, int H, int W, int Cin, int Cout, int k, int stride,
+                             float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x_planes || !w || !y || !x_amax || !workspace) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cin, Cout, k, stride) || ldy < Cout || (ldy & 3)) return Y4_ERR_SHAPE;
+    if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
+    if (workspace_bytes < y4_conv2d_fwd_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return Y4_ERR_SHAPE;
+    const int pad = (k - 1) / 2;
+    const long long M = (long long)B * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
+    if (partials && partial_bytes < (size_t)((M + 255) / 256) * 2 * Cout * sizeof(float)) return Y4_ERR_WORKSPACE;
+    hipStream_t st = y4_stream(stream);
+    unsigned* hdr = static_cast<unsigned*>(workspace);
+    unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + 64 + 4096);
+    int rc = y4::f16x2_filter_planes(w, planes, Cout, k * k * Cin, hdr, hdr + 16, st);
+    if (rc != Y4_OK) return rc;
+    int np = 0;
+    rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, nullptr, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st);
+    if (nparts_host) *nparts_host = np;
+    return rc;
+}
+
+
+// dgrad of a stride-1 conv over dy planes: the forward kernel on the mirrored, transposed filter (N = Cin, K = k*k*Cout)
+int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx, int lddx,
+                               int B, int H, int W, int Cin, int Cout, int k,
+                               void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
+                               const float* residual, int ldr, void* stream) {
+    if (!dy_planes || !w || !dx || !dy_amax || !workspace) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cout, Cin, k, 1) || lddx < Cin || (lddx & 3)) return Y4_ERR_SHAPE;
+    if (residual && (ldr < Cin || (ldr & 3) || (reinterpret_cast<uintptr_t>(residual) & 15))) return Y4_ERR_SHAPE;
+    if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
+    if (workspace_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+    if ((reinterpret_cast<uintptr_t>(dy_planes) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
+        (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(dx) & 15)) return Y4_ERR_SHAPE;
+    hipStream_t st = y4_stream(stream);
+    const long long total = (long long)Cin * k * k * Cout;
+    unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)total * 6);
+    int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout, hdr, hdr + 16, st, true);
+    if (rc != Y4_OK) return rc;
+    return y4::planes_conv(dy_planes, dy_amax, workspace, hdr, dx, lddx, residual, ldr, nullptr, nullptr, B, H, W, Cout, Cin, k, 1, st);
+}
+
+size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0) return 0;
+    int ntn, ntj, splits, sps;
+    y4::planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps);
+    return (splits > 1 ? (size_t)splits * Cout * k * k * Cin * sizeof(float) : 0) + 64;
+}
+
+int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, float* dw,
+                               int B, int H, int W, int Cin, int Cout, int k,
+                               void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
+                               void* stream) {
+    if (!x_planes || !dy_planes || !dw || !x_amax || !dy_amax) return Y4_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31) || (k != 1 && k != 3)) return Y4_ERR_SHAPE;
+    if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(dy_planes) & 15) ||
+        (reinterpret_cast<uintptr_t>(dw) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return Y4_ERR_SHAPE;
+    if (workspace_bytes < y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+    return y4::planes_wgrad(x_planes, x_amax, dy_planes, dy_amax, dw, workspace, workspace_bytes, B, H, W, Cin, Cout, k, y4_stream(stream));
+}
+
+}  // extern "C"

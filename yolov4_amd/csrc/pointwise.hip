@@ -191,10 +191,21 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const float* __restrict__ res, long long ldr, float* __restrict__ z, long long ldz,
-    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, int planes) {
+    // planes = 0: z fp32, max|z| folded into *out_amax.  z == nullptr: measure only (max|z| into *out_amax, nothing stored).
+    // planes = 1: z receives the two fp16 pieces of the f16x2 split, per pixel and 32-channel K tile [64 B hi | 64 B lo]
+    //             (conv_planes.hip), scaled by the power of two that *out_amax -- measured by a previous launch -- implies.
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     unsigned amax = 0u;
+    float ps = 1.f;
+    if (planes) {
+        const unsigned e8 = (*out_amax >> 23) & 0xffu;
+        int se = 268 - (int)e8;                            // as f16x2_scale_exp (conv_f16x2.hip)
+        if (e8 == 0u || e8 == 255u) se = 127;
+        se = se < 2 ? 2 : (se > 252 ? 252 : se);
+        ps = __uint_as_float((unsigned)se << 23);
+    }
     for (int c0 = cv * 4; c0 < C; c0 += tpr * 4) {
         f32x4 a, b;
 #pragma unroll
@@ -208,11 +219,25 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = y4_act(v[e] * a[e] + b[e], act);
             if (res) o += ld4(res + m * ldr + c0);
-            st4(z + m * ldz + c0, o);
-            amax_track(amax, o);
+            if (planes) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = o[e] * ps;
+                    hi[e] = (_Float16)t;
+                    lo[e] = (_Float16)((t - (float)hi[e]) * 2048.f);
+                }
+                unsigned char* row = reinterpret_cast<unsigned char*>(z + m * ldz) + (c0 >> 5) * 128 + (c0 & 31) * 2;
+                *reinterpret_cast<h4*>(row) = hi;
+                *reinterpret_cast<h4*>(row + 64) = lo;
+            } else {
+                if (z) st4(z + m * ldz + c0, o);
+                amax_track(amax, o);
+            }
         }
     }
-    if (out_amax) amax_commit(amax, out_amax);
+    if (out_amax && !planes) amax_commit(amax, out_amax);
 }
 
 // backward pass 1: sum_g[c] = sum_m g, sum_gx[c] = sum_m g * xhat,  g = dz * act'(u)
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const double invM = 1.0 / (double)M;
     unsigned amax = 0u;
     // plane output (conv mode 3): dy leaves as the two fp16 pieces the conv kernels would otherwise split it into,
-    // per pixel [C hi halfs][C scaled-lo halfs] in the 4C bytes of the fp32 row.  The scale needs max|dy| BEFORE the
+    // per pixel and 32-channel K tile [64 B hi | 64 B scaled lo] in the 4C bytes of the fp32 row.  The scale needs max|dy| BEFORE the
     // sweep: |dy| <= max|gamma invstd| (max|g| + max|k1| + max|xhat| max|k2|), all five maxima left by the reduce /
     // finalize kernels in bounds[0..4]; the bound goes to bounds[5] for the consumers (same word -> same scale).
     float ps = 1.f;
@@ -384,13 +409,13 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
                 h01[0] = (_Float16)t0; h01[1] = (_Float16)t1; h23[0] = (_Float16)t2; h23[1] = (_Float16)t3;
                 l01[0] = (_Float16)((t0 - (float)h01[0]) * 2048.f); l01[1] = (_Float16)((t1 - (float)h01[1]) * 2048.f);
                 l23[0] = (_Float16)((t2 - (float)h23[0]) * 2048.f); l23[1] = (_Float16)((t3 - (float)h23[1]) * 2048.f);
-                unsigned short* row = reinterpret_cast<unsigned short*>(dy + m * lddy);
+                unsigned char* row = reinterpret_cast<unsigned char*>(dy + m * lddy) + (c0 >> 5) * 128 + (c0 & 31) * 2;
                 typedef unsigned u2 __attribute__((ext_vector_type(2)));
                 u2 hv, lv;
                 hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
                 lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
-                *reinterpret_cast<u2*>(row + c0) = hv;
-                *reinterpret_cast<u2*>(row + C + c0) = lv;
+                *reinterpret_cast<u2*>(row) = hv;          // per 32-channel K tile: [64 B hi | 64 B lo] (conv_planes.hip)
+                *reinterpret_cast<u2*>(row + 64) = lv;
             } else {
                 st4(dy + m * lddy + c0, o);
                 amax_track(amax, o);
@@ -756,16 +781,18 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, unsigned* out_amax, void* stream) {
-    if (!y || !mean || !invstd || !gamma || !beta || !z) return Y4_ERR_NULL;
-    if (!vec_ok(y, ldy, C) || !vec_ok(z, ldz, C) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
+                      long long M, int C, unsigned* out_amax, int z_planes, void* stream) {
+    if (!y || !mean || !invstd || !gamma || !beta) return Y4_ERR_NULL;
+    if (!z && (!out_amax || z_planes)) return Y4_ERR_NULL;                       // measure-only needs the word to fill
+    if (z_planes && (!out_amax || ldz != C || (C & 31))) return Y4_ERR_SHAPE;    // planes: dense rows, whole K tiles
+    if (!vec_ok(y, ldy, C) || (z && !vec_ok(z, ldz, C)) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
         return Y4_ERR_SHAPE;
     const RowMap rm = row_map(C);
     long long blocks = (M + rm.rpb - 1) / rm.rpb;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
                        (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
-                       M, C, rm.tpr, rm.rpb, out_amax);
+                       M, C, rm.tpr, rm.rpb, out_amax, z_planes ? 1 : 0);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

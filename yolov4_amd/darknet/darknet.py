@@ -49,15 +49,17 @@ class ConvBNAct(nn.Module):
         self.stride = stride
         self.has_bn = bool(bn)
 
-    def forward(self, x, residual=None, out=None, dres_put=None, dres_take=None):
+    def forward(self, x, residual=None, out=None, dres_put=None, dres_take=None, out_planes=False):
         """out: optional destination (a CatBuffer slot) for the activation; dres_put / dres_take: the shared box through
-        which a ResBlock unit's 3x3 conv hands the skip gradient to its 1x1 conv (see ResBlock).  The reference has
-        none of these arguments."""
+        which a ResBlock unit's 3x3 conv hands the skip gradient to its 1x1 conv (see ResBlock); out_planes: the caller
+        guarantees that the SOLE consumer of the result is a ConvBNAct for which `takes_planes()` holds, so the
+        activation may leave pre-split for the DMA-fed conv kernels (csrc/conv_planes.hip) instead of as fp32.  The
+        reference has none of these arguments."""
         n = self.norm
         io = {}
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
-               'dres_put': dres_put, 'dres_take': dres_take,
+               'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': bool(out_planes),
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:
             use_batch_stats = self.training or n.running_mean is None
@@ -80,7 +82,31 @@ class ConvBNAct(nn.Module):
             w = self.conv.weight
         cfg['weight_param'] = self.conv.weight       # its gradient may be produced on the side stream (ops._wgrad_to_param)
         z = ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
+        if io.get('z_planes'):
+            z.y4_planes = True                       # (tags do not survive autograd's output wrapping: set on the result)
         return ops.tag_amax(z, io.get('z_amax'))
+
+
+def takes_planes(m):
+    """True if ConvBNAct `m` can consume a pre-split (planes) input right now: training-mode BatchNorm, conv mode 3,
+    stride 1, whole 32-channel K tiles on both sides and at least one full 128-column tile of output channels (all three
+    of its convs then run on the DMA kernels of csrc/conv_planes.hip)."""
+    if not isinstance(m, ConvBNAct) or not m.has_bn or not m.training or m.stride != 1:
+        return False
+    ci, co = m.conv.in_channels, m.conv.out_channels
+    if ci % 32 or co % 32 or co < 128 or ci < 64 or m.kernel_size not in (1, 3):
+        return False
+    return ops.PLANES['on'] and ops.f16x2_mode() and m.conv.weight.is_cuda
+
+
+def chain(seq, x):
+    """nn.Sequential of ConvBNAct layers, each feeding only the next: intermediates leave pre-split where the consumer
+    can take them (same results as seq(x); the reference calls the Sequential)."""
+    mods = list(seq)
+    for i, m in enumerate(mods):
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        x = m(x, out_planes=nxt is not None and takes_planes(nxt)) if isinstance(m, ConvBNAct) else m(x)
+    return x
 
 
 def res_unit(pair, x):
@@ -89,7 +115,7 @@ def res_unit(pair, x):
     separate elementwise pass."""
     xa, xb = ops.fork(x)
     box = {} if (torch.is_grad_enabled() and xa.requires_grad and pair[0].training) else None
-    return pair[1](pair[0](xa, dres_take=box), residual=xb, dres_put=box)
+    return pair[1](pair[0](xa, dres_take=box, out_planes=takes_planes(pair[1])), residual=xb, dres_put=box)
 
 
 class ResBlock(nn.Module):

@@ -135,6 +135,24 @@ def new_amax(device, n=1):
     return cell
 
 
+# Pre-split operands for the DMA-fed conv kernels (csrc/conv_planes.hip); Y4_PLANES=0 keeps every tensor fp32 (A/B runs)
+PLANES = {'on': os.environ.get('Y4_PLANES', '1') != '0'}
+_PCELLS = {}
+
+
+def planes_cell(device, n=8):
+    """n zeroed device words for a PLANE tensor's scale.  Unlike ring cells these are never recycled: a pre-split tensor
+    cannot be measured again, so its cell must live exactly as long as the tensor (the views keep their block alive)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    st = _PCELLS.get(key)
+    if st is None or st['i'] + n > st['buf'].numel():
+        st = {'buf': torch.zeros(2048, dtype=torch.int32, device=device), 'i': 0}
+        _PCELLS[key] = st
+    cell = st['buf'][st['i']:st['i'] + n]
+    st['i'] += n
+    return cell
+
+
 def live(cell):
     """cell if its words still belong to it, else None (its ring half was recycled: a tensor held across ~4096 cell
     allocations -- cached features, many forwards before one backward).  The holder then takes the maximum again
@@ -269,6 +287,106 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     return y, mean, invstd
 
 
+# ------------------------------------------------------------------ pre-split operands ("planes", csrc/conv_planes.hip)
+class Planes:
+    """An NHWC activation stored as the two fp16 pieces of the f16x2 split: per pixel and 32-channel K tile
+    [64 B hi | 64 B lo] (4 bytes per element, like fp32), with the device word that fixes its power-of-two scale."""
+    __slots__ = ('buf', 'shape', 'amax')
+
+    def __init__(self, buf, shape, amax):
+        self.buf, self.shape, self.amax = buf, tuple(shape), amax
+
+
+def planes_split_raw(x, amax=None):
+    """fp32 NHWC tensor -> Planes (one read + one write pass; tensors whose producer does not emit planes itself)."""
+    L = lib()
+    B, C, H, W = x.shape
+    x, ldx = as_nhwc(x)
+    if amax is None:
+        amax = amax_of(x)
+    if amax is None:
+        amax = amax_raw(x)
+    buf = torch.empty((B, H, W, C * 4), dtype=torch.uint8, device=x.device)
+    check(L.y4_planes_split_f32(_ptr(x), ldx, B * H * W, C, _ptr(amax), _ptr(buf), _stream()), 'planes_split')
+    return Planes(buf, (B, C, H, W), amax)
+
+
+def conv_fwd_planes_raw(xp, w, k, s, stats=True):
+    """Training-mode conv over a Planes input: raw output y (+ per-256-row-tile column sums, n_tiles)."""
+    L = lib()
+    B, Cin, H, W = xp.shape
+    Cout = w.shape[0]
+    Ho, Wo = conv_out_hw(H, W, k, s)
+    y = empty_nhwc(B, Cout, Ho, Wo, xp.buf.device)
+    w = krsc(w)
+    nbytes = L.y4_conv2d_fwd_workspace(Cin, Cout, k)
+    ws = _ws(nbytes, xp.buf.device)
+    pbytes = ((B * Ho * Wo + 255) // 256) * 2 * Cout * 4 if stats else 0
+    part = _ws(pbytes, xp.buf.device) if stats else None
+    n = ctypes.c_longlong(0)
+    check(L.y4_conv2d_fwd_planes_f32(_ptr(xp.buf), _ptr(w), _ptr(y), nhwc_pitch(y), B, H, W, Cin, Cout, k, s,
+                                     _ptr(part), pbytes, ctypes.byref(n), _ptr(xp.amax), _ptr(ws), nbytes, _stream()),
+          'conv2d_fwd_planes')
+    return (y, part, n.value) if stats else y
+
+
+def conv_fwd_planes_bnstats_raw(xp, w, k, s, running_mean, running_var, nbt, momentum, eps):
+    """conv_fwd_bnstats_raw over a Planes input: (y, mean, invstd)."""
+    L = lib()
+    y, part, nparts = conv_fwd_planes_raw(xp, w, k, s)
+    Cout = w.shape[0]
+    M = y.shape[0] * y.shape[2] * y.shape[3]
+    mean = torch.empty(Cout, device=y.device, dtype=torch.float32)
+    invstd = torch.empty(Cout, device=y.device, dtype=torch.float32)
+    wsb = L.y4_bn_finalize_workspace(Cout)
+    ws = _ws(wsb, y.device)
+    check(L.y4_bn_finalize_partials_f32(_ptr(part), nparts, M, Cout, _ptr(mean), _ptr(invstd),
+                                        _ptr(running_mean), _ptr(running_var), _ptr(nbt), float(momentum), float(eps),
+                                        _ptr(ws), wsb, _stream()), 'bn_finalize_partials')
+    return y, mean, invstd
+
+
+def planes_of(t):
+    """Planes view of a tensor written pre-split by bn_act_fwd_raw / bn_act_bwd_raw (tag y4_planes); None otherwise."""
+    if t is None or not getattr(t, 'y4_planes', False):
+        return None
+    return Planes(t, t.shape, t.y4_amax)
+
+
+def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None):
+    """dx of a stride-1 conv from a Planes dy (the DMA forward kernel on the mirrored transposed filter)."""
+    L = lib()
+    B, Cin, H, W = x_shape
+    Cout = w.shape[0]
+    dx = empty_nhwc(B, Cin, H, W, dyp.buf.device)
+    nbytes = L.y4_conv2d_dgrad_workspace(Cin, Cout, k)
+    ws = _ws(nbytes, dyp.buf.device)
+    ldr = 0
+    if residual is not None:
+        residual, ldr = as_nhwc(residual)
+    check(L.y4_conv2d_dgrad_planes_f32(_ptr(dyp.buf), _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k,
+                                       _ptr(ws), nbytes, _ptr(dyp.amax), _ptr(residual), ldr, _stream()), 'conv2d_dgrad_planes')
+    return dx
+
+
+def conv_wgrad_planes_raw(xp, dyp, w_shape, k, out=None):
+    """dW of a stride-1 conv from Planes x and dy; `out` as conv_wgrad_raw."""
+    L = lib()
+    B, Cin, H, W = xp.shape
+    Cout = w_shape[0]
+    if out is not None and tuple(out.shape) == tuple(w_shape) and _is_krsc_dense(out) and out.data_ptr() % 16 == 0:
+        dw = out
+        WGRAD_STATS['in_place'] += 1
+    else:
+        WGRAD_STATS['temporary'] += 1
+        dw = krsc(torch.empty(w_shape, device=xp.buf.device, dtype=torch.float32).contiguous(memory_format=CL))
+    nbytes = L.y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k)
+    ws = _ws(nbytes, xp.buf.device)
+    check(L.y4_conv2d_wgrad_planes_f32(_ptr(xp.buf), _ptr(dyp.buf), _ptr(dw), B, H, W, Cin, Cout, k, _ptr(ws), nbytes,
+                                       _ptr(xp.amax), _ptr(dyp.amax), _stream()), 'conv2d_wgrad_planes')
+    return dw
+
+
 def last_conv_kernel():
     """Symbol (as rocprofv3 prints it) of the conv kernel this thread launched last, '' if unknown; measurement aid."""
     import ctypes
@@ -277,7 +395,7 @@ def last_conv_kernel():
     return buf.value.decode()
 
 
-def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=False):
+def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None):
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
@@ -290,7 +408,7 @@ def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, dy_planes=
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
     check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
-                                _ptr(ws), nbytes, _ptr(dy_amax), 1 if dy_planes else 0, _ptr(residual), ldr, _stream()),
+                                _ptr(ws), nbytes, _ptr(dy_amax), _ptr(residual), ldr, _stream()),
           'conv2d_dgrad')
     return dx
 
@@ -305,10 +423,10 @@ def _is_krsc_dense(t):
 
 
 WGRAD_STATS = {'in_place': 0, 'temporary': 0}
-DY_PLANES = {'dgrad': os.environ.get('Y4_DY_PLANES', '0') == '1'}      # experimental: see ConvBNActFn.backward      # filter gradients written into a caller slot vs a temporary
 
 
-def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None, dy_planes=False):
+
+def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None):
     """out: optional fp32 tensor of shape w_shape whose memory is dense KRSC (e.g. a gradient slot of a flat
     DDP bucket): the kernel then writes the filter gradient in place."""
     L = lib()
@@ -334,7 +452,7 @@ def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None, dy
     nbytes = L.y4_conv2d_wgrad_workspace(B, H, W, Cin, Cout, k, s)
     ws = _ws(nbytes, dy.device)
     check(L.y4_conv2d_wgrad_f32(_ptr(x), ldx, _ptr(dy), lddy, _ptr(dw), B, H, W, Cin, Cout, k, s,
-                                _ptr(ws), nbytes, _ptr(x_amax), _ptr(dy_amax), 1 if dy_planes else 0, _stream()), 'conv2d_wgrad')
+                                _ptr(ws), nbytes, _ptr(x_amax), _ptr(dy_amax), _stream()), 'conv2d_wgrad')
     return dw
 
 
@@ -361,16 +479,26 @@ def _slot_ok(out, shape):
             and out.data_ptr() % 16 == 0)
 
 
-def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None):
+def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None, planes=False):
+    """planes: z leaves PRE-SPLIT for the plane conv kernels (a float32-typed tensor whose 4 bytes per element hold the two
+    fp16 pieces; tagged y4_planes) -- two launches: measure max|z| into a fresh cell, then write with that scale."""
     L = lib()
     B, C, H, W = y.shape
     y, ldy = as_nhwc(y)
-    z = out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual)
+    if planes:
+        cell = planes_cell(y.device)
+        z = empty_nhwc(B, C, H, W, y.device)
+        args = (_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act], _ptr(residual), ldr)
+        check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), 0, _stream()), 'bn_act_fwd(measure)')
+        check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), 1, _stream()), 'bn_act_fwd(planes)')
+        z.y4_planes = True
+        return tag_amax(z, cell)
+    z = out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)
     check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act],
-                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), _stream()), 'bn_act_fwd')
+                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), 0, _stream()), 'bn_act_fwd')
     return z
 
 
@@ -466,14 +594,14 @@ def join_side_stream(device=None):
     _ASYNC['join_queued'] = False
 
 
-def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None, dy_planes=False):
+def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None):
     """wgrad on the side stream, accumulated straight into param.grad (autograd gets None for this input)."""
     main = torch.cuda.current_stream(x.device)
     side = side_stream(x.device)
     ev = main.record_event()
     with torch.cuda.stream(side):
         side.wait_event(ev)
-        dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s, x_amax=x_amax, dy_amax=dy_amax, dy_planes=dy_planes)
+        dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s, x_amax=x_amax, dy_amax=dy_amax)
         if param.grad is None:
             dw.record_stream(main)          # allocated in the side stream's pool, consumed (and freed) on the main one
             param.grad = dw
@@ -513,22 +641,40 @@ class ConvBNActFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         # conv mode 3: operand maxima travel with the tensors (see "operand maxima" above)
         f16 = f16x2_mode() and x.shape[1] != 3
+        # pre-split operands (conv_planes.hip): x arrives as planes when its producer was asked to (out_planes, below);
+        # all three of this layer's convs then run on the DMA kernels, dy leaving the BatchNorm backward as planes too
+        xp = planes_of(x)
+        ctx.x_planes = xp is not None
+        if xp is not None and not (f16 and bn and training and s == 1 and weight.shape[0] % 32 == 0 and x.shape[1] % 32 == 0):
+            raise Y4Error('a pre-split (planes) tensor reached a conv that cannot consume it')
         x_amax = live(cfg.get('x_amax')) if f16 else None
         z_amax = None
         io = cfg.get('io')
-        if f16 and x_amax is None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+        if xp is not None:
+            x_amax = xp.amax
+        elif f16 and x_amax is None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             x_amax = amax_raw(x)                     # needed twice (forward, wgrad): one pass here instead of two inside
         ctx.x_amax = x_amax
         if bn and training:
             if x.shape[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[1] <= 1:
                 raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
-            y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
-                                                   cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax)
-            if f16x2_mode():
-                z_amax = live(cfg.get('out_amax')) if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
-                if z_amax is None:
-                    z_amax = new_amax(x.device)
-            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
+            if xp is not None:
+                y, mean, invstd = conv_fwd_planes_bnstats_raw(xp, weight, k, s, cfg['running_mean'], cfg['running_var'],
+                                                              cfg['nbt'], cfg['momentum'], cfg['eps'])
+            else:
+                y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
+                                                       cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax)
+            if cfg.get('out_planes') and f16 and dest is None and y.shape[1] % 32 == 0:
+                z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, planes=True)
+                z_amax = z.y4_amax
+                if io is not None:
+                    io['z_planes'] = True
+            else:
+                if f16x2_mode():
+                    z_amax = live(cfg.get('out_amax')) if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
+                    if z_amax is None:
+                        z_amax = new_amax(x.device)
+                z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
             ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
         elif bn:
@@ -565,21 +711,21 @@ class ConvBNActFn(torch.autograd.Function):
         k, s, act = cfg['k'], cfg['s'], cfg['act']
         f16 = f16x2_mode() and ctx.x_shape[1] != 3
         dy_amax = None
-        dy_planes = False
         x_amax = live(ctx.x_amax)                     # None if the ring recycled it since forward: wgrad takes its own pass
+        x_planes = getattr(ctx, 'x_planes', False)
         if ctx.mode == 'bn_train':
             x, weight, y, mean, invstd, gamma, beta = ctx.saved_tensors
             gp, bp = cfg.get('gamma_param'), cfg.get('beta_param')
             sink = (gp is not None and bp is not None and getattr(gp, '_y4_grad_fresh', False)
                     and getattr(bp, '_y4_grad_fresh', False) and gp.grad is not None and bp.grad is not None
                     and ctx.needs_input_grad[3] and ctx.needs_input_grad[4])
-            # conv mode 3: dy leaves the BatchNorm backward sweep already split into its two fp16 planes (DY_PLANES)
-            planes = new_amax(dz.device, 8) if (f16 and DY_PLANES['dgrad'] and y.shape[1] % 32 == 0) else None
+            # a layer whose input came pre-split runs dgrad and wgrad on the plane kernels: dy leaves the BatchNorm
+            # backward sweep already split, scaled by a bound of max|dy| the reduce pass derives (word [5] of the cell)
+            planes = planes_cell(dz.device, 8) if x_planes else None
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                                gp.grad if sink else None, bp.grad if sink else None,
                                                out_amax=None if planes is not None else dy_amax, planes=planes)
-            dy_planes = planes is not None
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
                 gp._y4_grad_fresh = bp._y4_grad_fresh = False
@@ -605,25 +751,33 @@ class ConvBNActFn(torch.autograd.Function):
                 raise Y4Error('gradient wrt the network input (stem, Cin=3) is not implemented')
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
-            dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad, dy_planes=dy_planes)
+            if x_planes:
+                dx = conv_dgrad_planes_raw(Planes(dy, dy.shape, dy_amax), weight, ctx.x_shape, k, residual=skip_grad)
+            else:
+                dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad)
         elif skip_grad is not None:
             raise Y4Error('a parked skip gradient has no consumer (input of the 1x1 conv does not require grad)')
         dw = None
         if ctx.needs_input_grad[1]:
             param = cfg.get('weight_param')
-            if _ASYNC['on'] and param is not None and param.requires_grad:
-                _wgrad_to_param(x, dy, param, k, s, x_amax, dy_amax, dy_planes)   # lands in param.grad on the side stream
+
+            def wgrad(out=None):
+                if x_planes:
+                    return conv_wgrad_planes_raw(Planes(x, x.shape, ctx.x_amax), Planes(dy, dy.shape, dy_amax),
+                                                 tuple(weight.shape), k, out=out)
+                return conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=out, x_amax=x_amax, dy_amax=dy_amax)
+            if _ASYNC['on'] and param is not None and param.requires_grad and not x_planes:
+                _wgrad_to_param(x, dy, param, k, s, x_amax, dy_amax)   # lands in param.grad on the side stream
             elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
                 # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place
                 # (no temporary, no accumulate pass); the bucket is told directly, autograd gets None
                 param._y4_grad_fresh = False
-                got = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=param.grad, x_amax=x_amax, dy_amax=dy_amax,
-                                     dy_planes=dy_planes)
+                got = wgrad(out=param.grad)
                 if got is not param.grad:
                     param.grad.add_(got)
                 param._y4_grad_ready()
             else:
-                dw = conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, x_amax=x_amax, dy_amax=dy_amax, dy_planes=dy_planes)
+                dw = wgrad()
         dres = dz if ctx.has_res else None
         put = cfg.get('dres_put')
         if dres is not None and put is not None:

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from ... import ops
-from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample
+from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain
 from .yololayer import YOLOLayer
 
 L = 'leaky_relu'
@@ -57,7 +57,7 @@ class SPPBlock(nn.Module):
         self.conv2 = ConvBNAct(2048, 512, 1, 1, act=L)
 
     def forward(self, x):
-        return self.conv2(ops.spp_pool_cat(self.conv1(x)))
+        return self.conv2(ops.spp_pool_cat(chain(self.conv1, x)))
 
 
 class Upsample(nn.Module):
@@ -103,19 +103,19 @@ class FPNBlock(nn.Module):
         self.module3 = _five(256, 128)
 
     def forward(self, x3, x4, x5):
-        f3 = self.module1(x5)
+        f3 = chain(self.module1, x5)
         f3a, f3b = ops.fork(f3)
         cb = ops.cat_buffer(x4, [256, 256])                      # [conv4(x4) | upsampled conv3(f3)], written in place
         up = self.upsample1(self.conv3(f3a), x4.size(), out=cb.slot(1))
         x4 = self.conv4(x4, out=cb.slot(0))
         assert up.shape[2:] == x4.shape[2:]
-        f2 = self.module2(ops.cat([x4, up], into=cb))
+        f2 = chain(self.module2, ops.cat([x4, up], into=cb))
         f2a, f2b = ops.fork(f2)
         cb = ops.cat_buffer(x3, [128, 128])
         up = self.upsample2(self.conv10(f2a), x3.size(), out=cb.slot(1))
         x3 = self.conv11(x3, out=cb.slot(0))
         assert up.shape[2:] == x3.shape[2:]
-        f1 = self.module3(ops.cat([x3, up], into=cb))
+        f1 = chain(self.module3, ops.cat([x3, up], into=cb))
         return f1, f2b, f3b
 
 
@@ -133,12 +133,12 @@ class PANBlock(nn.Module):
         cb = ops.cat_buffer(f2, [256, f2.shape[1]])
         p2 = self.conv1(f1b, out=cb.slot(0))
         assert p2.shape[2:] == f2.shape[2:]
-        p2 = self.module1(ops.cat([p2, f2], into=cb))
+        p2 = chain(self.module1, ops.cat([p2, f2], into=cb))
         p2a, p2b = ops.fork(p2)
         cb = ops.cat_buffer(f3, [512, f3.shape[1]])
         p3 = self.conv7(p2a, out=cb.slot(0))
         assert p3.shape[2:] == f3.shape[2:]
-        p3 = self.module2(ops.cat([p3, f3], into=cb))
+        p3 = chain(self.module2, ops.cat([p3, f3], into=cb))
         return p1, p2b, p3
 
 
