@@ -215,11 +215,15 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
  * z == NULL: measure only (max|z| into *out_amax, nothing stored).
  * z_planes != 0: z (ldz == C, C % 32 == 0) receives the tensor PRE-SPLIT for the plane conv kernels -- per pixel and
  * 32-channel K tile [64 B: hi halfs | 64 B: scaled lo halfs], 4 bytes per element -- scaled by the power of two that
- * *out_amax implies; *out_amax must already hold max|z| or an upper bound (a measure-only call on the same arguments). */
+ * *out_amax implies.  z_planes == 1: *out_amax must already hold max|z| or an upper bound (e.g. a measure-only call on the
+ * same arguments).  z_planes == 2: the call derives the bound itself, without a pass over the data -- |xhat| <= sqrt(M - 1)
+ * for any sample of M values, |act(v)| <= |v|, so |z| <= max_c(|gamma_c| sqrt(M - 1) + |beta_c|) + max|residual|
+ * (res_amax: the residual's maximum word, required with a residual) -- and leaves it in *out_amax for the consumers.  A
+ * loose bound costs the split only headroom (full precision down to 2^-29 of the bound). */
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, unsigned* out_amax, int z_planes, void* stream);
+                      long long M, int C, unsigned* out_amax, int z_planes, const unsigned* res_amax, void* stream);
 /* Backward of the two ops above wrt y, gamma, beta given dz (grad wrt z; the residual branch
  * receives dz itself).  dy may alias dz.  workspace: y4_bn_workspace(M, C) bytes. */
 int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
@@ -307,6 +311,16 @@ int y4_yolo_loss_dense_targets_f32(float* target, float* tgt_mask, float* tgt_sc
                                    int B, int F, int A, int K, int n_classes,
                                    const void* workspace, size_t workspace_bytes, void* stream);
 
+/* Device-side prefix sums of postprocess (no host round trip between its stages):
+ * y4_post_scan_i32: seg_offsets[0..n_segments] = exclusive scan of the candidate counts, clamped to `cap` (the capacity, in
+ *   candidates, of the buffers the caller allocated: a too-small capacity truncates segments, it never overflows);
+ *   info[0] = true total, info[1] = 1 if it exceeds cap (the caller then repeats the call sequence with cap >= info[0]).
+ * y4_post_compact_f32: out_offsets = exclusive scan of `kept`; rows of every segment copied to out_rows back to back
+ *   (class ascending, score descending inside an image, utils.py:200-221); img_offsets[b] = first output row of image b,
+ *   img_offsets[B] = number of detections.  One device->host copy of img_offsets (+ info) is the call's only sync. */
+int y4_post_scan_i32(const int* counts, int n_segments, long long cap, int* seg_offsets, int* info, void* stream);
+int y4_post_compact_f32(const float* det_rows, const int* seg_offsets, const int* kept, int B, int n_classes,
+                        float* out_rows, int* out_offsets, int* img_offsets, void* stream);
 /* ---------------------------------------------------------------- post-processing
  * Replaces postprocess + nms, yolo/util/utils.py:32-89,92-223.
  * Stage 1: xywh->xyxy in place on prediction [B,N,5+C] and count candidates

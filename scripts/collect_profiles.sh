@@ -1,10 +1,10 @@
 #!/bin/bash
 # Collects the round's measurement artefacts on a 1-GPU MI355X box (run from the repo root through gpurun):
 # kernel stats + PMC passes of the training bench, the inference leg, and the one-rank RCCL rehearsal.
-# Outputs land in gpurun_out/r02/; the summaries worth keeping are copied into profiles/ by hand.
+# Outputs land in gpurun_out/r03/ (every pass keeps its own stderr file); the summaries worth keeping are copied into profiles/ by hand.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${Y4_ROUND:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 STEPS="--steps 5 --warmup 2 --no-cpu-baseline"

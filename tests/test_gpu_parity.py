@@ -571,6 +571,32 @@ def test_postprocess_golden(dev, golden):
                     assert torch.equal(out[b].cpu(), torch.from_numpy(g[f'det{case}_{b}']))   # survivors + order: exact
 
 
+def test_postprocess_many_classes_and_candidate_overflow(dev):
+    """with 243..250 classes the LDS-tiled count kernel would need more than the 64-KiB default (tile + two
+    histograms): the launcher must take the row-per-thread kernel instead.  And a threshold low enough for MANY classes per
+    box overflows the first candidate-buffer guess (B*N/2): the call must notice on its one host read and repeat with
+    room.  Both against the oracle, survivors and order exact."""
+    from yolov4_amd.yolo.util.utils import postprocess
+    rng = np.random.RandomState(5)
+    for C, N, conf in ((250, 300, 0.3), (80, 1500, 0.002)):
+        B = 2
+        p = np.zeros((B, N, 5 + C), dtype=np.float32)
+        p[..., 0:2] = rng.uniform(50, 550, (B, N, 2))
+        p[..., 2:4] = rng.uniform(10, 200, (B, N, 2))
+        p[..., 4] = rng.uniform(0.05, 1.0, (B, N))
+        p[..., 5:] = rng.uniform(0, 1, (B, N, C)) ** (2 if conf < 0.01 else 6)
+        ref = H.postprocess(p.copy(), C, conf, 0.45)
+        got = postprocess(torch.from_numpy(p.copy()).to(dev), C, conf, 0.45)
+        ncand = int(((p[..., 5:] * p[..., 4:5]) >= conf).sum())
+        if C == 80:
+            assert ncand > max(B * N // 2, 1 << 16), ncand          # really exercises the overflow path
+        for b in range(B):
+            assert (ref[b] is None) == (got[b] is None)
+            if ref[b] is not None:
+                assert got[b].shape == ref[b].shape
+                assert np.array_equal(got[b].cpu().numpy(), ref[b])
+
+
 def test_nms_golden(dev, golden):
     from yolov4_amd.yolo.util.utils import nms
     g = golden('iou_nms')
@@ -814,6 +840,33 @@ def test_model_matches_oracle_at_608(dev, golden, hip_model):
         close(a, b, 2e-4, 1e-3)
 
 
+def _iou_xyxy(b, others):
+    tl = np.maximum(b[None, :2], others[:, :2]); br = np.minimum(b[None, 2:4], others[:, 2:4])
+    inter = np.prod(np.clip(br - tl, 0, None), 1) * (tl < br).all(1)
+    return inter / (np.prod(b[2:4] - b[:2]) + np.prod(others[:, 2:4] - others[:, :2], 1) - inter)
+
+
+def _assert_difference_is_a_near_tie(a, r, pred, conf, nms_thre, tol=2e-4):
+    """a, r: two [n,7] survivor lists that should be equal; pred [N,85] (xyxy already).  Every row present in only one of
+    them must owe that to a decision within `tol` of its threshold: its score within tol of conf, or its IoU with some
+    same-class candidate of higher score within tol of nms_thre (suppressed in one run, kept in the other)."""
+    def key(row):
+        return (int(row[6]), round(float(row[0]), 1), round(float(row[1]), 1))
+    ka, kr = {key(x): x for x in a}, {key(x): x for x in r}
+    odd = [ka[k] for k in ka.keys() - kr.keys()] + [kr[k] for k in kr.keys() - ka.keys()]
+    assert 0 < len(odd) <= 4, len(odd)
+    for row in odd:
+        c = int(row[6])
+        score = row[4] * row[5]
+        if abs(score - conf) <= tol * max(conf, 1e-6):
+            continue
+        sc = pred[:, 4] * pred[:, 5 + c]
+        cand = pred[(sc >= conf) & (sc > score)][:, :4]
+        assert len(cand), row
+        iou = _iou_xyxy(row[:4], cand)
+        assert np.abs(iou - nms_thre).min() <= tol, (row, float(np.abs(iou - nms_thre).min()))
+
+
 def test_eval_batch_independence_at_config2_size(dev, golden, hip_model):
     """BASELINE configs[1] size (608x608, bs=32, eval): every image of the batch must come out as it does alone.
     Size-independent property at the full configuration (the oracle needs ~1 s per image on the host; the single-image
@@ -841,8 +894,12 @@ def test_eval_batch_independence_at_config2_size(dev, golden, hip_model):
                 da = postprocess(full[i:i + 1].clone(), 80, thr, 0.45)[0]
                 db = postprocess(one.clone(), 80, thr, 0.45)[0]
                 assert (da is None) == (db is None)
+                if da is not None and da.shape != db.shape:
+                    # the two runs differ by rounding (2e-5, checked above): a survivor set may differ ONLY where a
+                    # decision sat within that rounding of its threshold -- proven here for every odd row out
+                    _assert_difference_is_a_near_tie(da.cpu().numpy(), db.cpu().numpy(), one[0].cpu().numpy(), thr, 0.45)
+                    continue
                 if da is not None:
-                    assert da.shape == db.shape
                     assert torch.equal(da[:, 6], db[:, 6])                   # same classes, same count per class
                     # scores agree to rounding only, so two near-tied boxes of one class may swap places in the
                     # score-ordered output: compare each class as a set (rows sorted by x1)

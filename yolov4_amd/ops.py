@@ -481,7 +481,8 @@ def _slot_ok(out, shape):
 
 def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None, planes=False):
     """planes: z leaves PRE-SPLIT for the plane conv kernels (a float32-typed tensor whose 4 bytes per element hold the two
-    fp16 pieces; tagged y4_planes) -- two launches: measure max|z| into a fresh cell, then write with that scale."""
+    fp16 pieces; tagged y4_planes), scaled by an analytic bound of max|z| that the call leaves in the tensor's cell (no
+    measuring pass; with a residual whose maximum is unknown: one measure-only launch first)."""
     L = lib()
     B, C, H, W = y.shape
     y, ldy = as_nhwc(y)
@@ -492,13 +493,19 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
         cell = planes_cell(y.device)
         z = empty_nhwc(B, C, H, W, y.device)
         args = (_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act], _ptr(residual), ldr)
-        check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), 0, _stream()), 'bn_act_fwd(measure)')
-        check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), 1, _stream()), 'bn_act_fwd(planes)')
+        res_cell = amax_of(residual) if residual is not None else None
+        if residual is not None and res_cell is None:
+            check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), 0, None, _stream()), 'bn_act_fwd(measure)')
+            mode = 1
+        else:
+            mode = 2
+        check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), mode, _ptr(res_cell), _stream()),
+              'bn_act_fwd(planes)')
         z.y4_planes = True
         return tag_amax(z, cell)
     z = out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)
     check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act],
-                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), 0, _stream()), 'bn_act_fwd')
+                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), 0, None, _stream()), 'bn_act_fwd')
     return z
 
 

@@ -2,8 +2,9 @@
 """Post-processing behind the reference's API (yolo/util/utils.py:32-89, 92-223):
 confidence filter + per-class greedy NMS on the GPU.
 
-Two host round trips per call (candidate counts, survivor counts) replace the
-reference's per-class device->host copies and its Python/numpy loops.  Tie order is
+One host round trip per call (per-image offsets of the compacted result) replaces the
+reference's per-class device->host copies and its Python/numpy loops: candidate prefix
+sums, key fill, sort + NMS and compaction all run on the device.  Tie order is
 DEFINED here (score desc, then lower box index first); the reference's comes from an
 unstable numpy argsort and is platform dependent.
 """
@@ -67,29 +68,38 @@ def postprocess(prediction, num_classes, conf_thre=0.7, nms_thre=0.45):
           'post_count')
     if on_host:
         src[:, :, :4] = prediction[:, :, :4].cpu()
-    cnt = counts.cpu().numpy().astype(np.int64)                       # host sync 1
-    offs = np.zeros(nseg + 1, dtype=np.int64)
-    np.cumsum(cnt, out=offs[1:])
-    total = int(offs[-1])
-    if total == 0:
-        return out
-    seg_off = torch.from_numpy(offs.astype(np.int32)).to(dev)
-    rows = torch.empty((total, 7), dtype=torch.float32, device=dev)
+    # Everything between the count and the result stays on the device: prefix sums, key fill, sort + NMS, compaction run
+    # into buffers sized for `cap` candidates; the ONE host read at the end brings the per-image offsets and the true
+    # candidate total (if it exceeded cap -- many classes per box above a low threshold -- the sequence repeats with room).
+    cap = int(min(B * N * num_classes, max(B * N // 2, 1 << 16), (1 << 31) - 1))
+    seg_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
+    meta = torch.empty(2 + B + 1, dtype=torch.int32, device=dev)          # [total, overflow | img_off[0..B]]
+    out_off = torch.empty(nseg + 1, dtype=torch.int32, device=dev)
     kept = torch.empty(nseg, dtype=torch.int32, device=dev)
-    nbytes = L.y4_post_nms_workspace(total, nseg)
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(L.y4_post_nms_f32(ops._ptr(prediction), B, N, num_classes, float(conf_thre), float(nms_thre),
-                            ops._ptr(seg_off), total, ops._ptr(rows), ops._ptr(kept), ops._ptr(ws), nbytes, st),
-          'post_nms')
-    kept_h = kept.cpu().numpy().astype(np.int64)                      # host sync 2
+    while True:
+        check(L.y4_post_scan_i32(ops._ptr(counts), nseg, cap, ops._ptr(seg_off), ops._ptr(meta), st), 'post_scan')
+        rows = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+        final = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+        nbytes = L.y4_post_nms_workspace(cap, nseg)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(L.y4_post_nms_f32(ops._ptr(prediction), B, N, num_classes, float(conf_thre), float(nms_thre),
+                                ops._ptr(seg_off), cap, ops._ptr(rows), ops._ptr(kept), ops._ptr(ws), nbytes, st), 'post_nms')
+        check(L.y4_post_compact_f32(ops._ptr(rows), ops._ptr(seg_off), ops._ptr(kept), B, num_classes, ops._ptr(final),
+                                    ops._ptr(out_off), ops._ptr(meta[2:]), st), 'post_compact')
+        host = meta.cpu().numpy().astype(np.int64)                        # the host sync
+        if not host[1]:
+            break
+        cap = int(host[0])
+    img_off = host[2:]
+    n_det = int(img_off[B])
+    if n_det == 0:
+        return out
+    dets = final[:n_det].clone()                                          # (lets the cap-sized buffers go)
+    if on_host:
+        dets = dets.cpu()
     for b in range(B):
-        idx = [np.arange(offs[s], offs[s] + kept_h[s]) for s in range(b * num_classes, (b + 1) * num_classes)
-               if kept_h[s] > 0]
-        if not idx:
-            continue
-        sel = torch.from_numpy(np.concatenate(idx)).to(dev)
-        det = rows.index_select(0, sel)
-        out[b] = det.cpu() if on_host else det
+        if img_off[b + 1] > img_off[b]:
+            out[b] = dets[img_off[b]:img_off[b + 1]]
     return out
 
 
