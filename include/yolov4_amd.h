@@ -219,11 +219,14 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
  * same arguments).  z_planes == 2: the call derives the bound itself, without a pass over the data -- |xhat| <= sqrt(M - 1)
  * for any sample of M values, |act(v)| <= |v|, so |z| <= max_c(|gamma_c| sqrt(M - 1) + |beta_c|) + max|residual|
  * (res_amax: the residual's maximum word, required with a residual) -- and leaves it in *out_amax for the consumers.  A
- * loose bound costs the split only headroom (full precision down to 2^-29 of the bound). */
+ * loose bound costs the split only headroom (full precision down to 2^-29 of the bound).
+ * planes_twin (nullable, with z_planes != 0): z stays fp32 (pitch ldz) and planes_twin [M][C] receives the pre-split copy --
+ * for a tensor that feeds both a plane-consuming conv and fp32 consumers (a fork in front of a detection head). */
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, unsigned* out_amax, int z_planes, const unsigned* res_amax, void* stream);
+                      long long M, int C, unsigned* out_amax, int z_planes, const unsigned* res_amax, float* planes_twin,
+                      void* stream);
 /* Backward of the two ops above wrt y, gamma, beta given dz (grad wrt z; the residual branch
  * receives dz itself).  dy may alias dz.  workspace: y4_bn_workspace(M, C) bytes. */
 int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,

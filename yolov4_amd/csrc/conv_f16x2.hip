@@ -1477,21 +1477,47 @@ __global__ __launch_bounds__(256) void f16x2_transpose_split_filter_folded_kerne
 }
 
 // ---- inference: a prepared filter buffer is refreshed only when the filter's BITS changed (exact 64-bit positional
-// checksum, order independent), decided on the device: no host sync, no version counters to trust.
+// checksum, order independent), decided on the device: no host sync, no version counters to trust.  ONE launch per call:
+// every block fingerprints its slice and takes a ticket; the last one folds the partials and compares with the header --
+// unchanged (every call but the first after a weight update): done; changed: that block re-splits the whole filter (rare,
+// so its serial cost -- at most 0.4 ms for the largest filter -- does not matter).
 //   header words: [0] max|w| bits  [1] scratch of the conv call  [2..3] checksum  [4] valid  [5] ticket
+// Hand-off (guide, Guideline 16): partials leave as agent-scope (write-through) stores, drained before the ticket; the
+// last block reads them with agent-scope loads behind a workgroup barrier.
 constexpr int FP_PARTS = 256;
-__global__ __launch_bounds__(256) void filter_fingerprint_kernel(const float* __restrict__ w, long long n,
-                                                                 unsigned* __restrict__ part_max,
-                                                                 unsigned long long* __restrict__ part_sum) {
+__global__ __launch_bounds__(256) void f16x2_refresh_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                                   long long n, unsigned* part_max, unsigned long long* part_sum,
+                                                                   unsigned* hdr) {
     __shared__ unsigned wmax[4];
     __shared__ unsigned long long wsum[4];
+    __shared__ int is_last;
     unsigned m = 0u;
     unsigned long long cs = 0ull;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const unsigned bits = __float_as_uint(w[i]);
-        cs += (unsigned long long)bits * (2ull * (unsigned long long)i + 1ull) + 0x9e3779b97f4a7c15ull;
+    auto take = [&](const float x, const unsigned long long i) {
+        const unsigned bits = __float_as_uint(x);
+        cs += (unsigned long long)bits * (2ull * i + 1ull) + 0x9e3779b97f4a7c15ull;
         const unsigned b = bits & 0x7fffffffu;
         if (b < 0x7f800000u && b > m) m = b;
+    };
+    {
+        // 16-B loads, four of them in flight per thread (a one-load-per-trip loop was latency-bound: 40 us per filter)
+        const long long n4 = n >> 2, stride = (long long)gridDim.x * blockDim.x;
+        long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(w + 4 * (i + u * stride));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) take(v[u][e], (unsigned long long)(4 * (i + u * stride) + e));
+        }
+        for (; i < n4; i += stride) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(w + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) take(v[e], (unsigned long long)(4 * i + e));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) take(w[(n4 << 2) + threadIdx.x], (unsigned long long)((n4 << 2) + threadIdx.x));
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1503,36 +1529,38 @@ __global__ __launch_bounds__(256) void filter_fingerprint_kernel(const float* __
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
-        part_max[blockIdx.x] = a > b ? a : b;
-        part_sum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __hip_atomic_store(part_max + blockIdx.x, a > b ? a : b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part_sum + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(hdr + 5, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t == gridDim.x - 1;
     }
-}
-__global__ __launch_bounds__(256) void f16x2_split_filter_if_changed_kernel(const float* __restrict__ w,
-                                                                            unsigned short* __restrict__ planes, long long n,
-                                                                            const unsigned* __restrict__ part_max,
-                                                                            const unsigned long long* __restrict__ part_sum,
-                                                                            int nparts, unsigned* __restrict__ hdr) {
-    __shared__ unsigned wmax[4];
-    __shared__ unsigned long long wsum[4];
-    unsigned m = threadIdx.x < nparts ? part_max[threadIdx.x] : 0u;
-    unsigned long long cs = threadIdx.x < nparts ? part_sum[threadIdx.x] : 0ull;
+    __syncthreads();
+    if (!is_last) return;
+    // ---- last block: fold, compare, (rarely) re-split
+    m = 0u; cs = 0ull;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        const unsigned v = __hip_atomic_load(part_max + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m = v > m ? v : m;
+        cs += __hip_atomic_load(part_sum + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned o = (unsigned)__shfl_xor((int)m, off, 64);
         m = o > m ? o : m;
         cs += __shfl_xor(cs, off, 64);
     }
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) { wmax[threadIdx.x >> 6] = m; wsum[threadIdx.x >> 6] = cs; }
     __syncthreads();
     const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
     const unsigned amax = a > b ? a : b;
     const unsigned long long sum = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    // every block reads the stored fingerprint BEFORE it takes its ticket; the last ticket holder rewrites the header
     const unsigned long long stored = (unsigned long long)hdr[2] | ((unsigned long long)hdr[3] << 32);
     const bool same = hdr[4] == 1u && stored == sum && hdr[0] == amax;
     if (!same) {
         const float s = __uint_as_float(f16x2_scale_exp(amax) << 23);
-        for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = threadIdx.x; i < n; i += 256) {
             unsigned short hi, lo;
             split2(w[i], s, hi, lo);
             const long long o = (i >> 5) * 64 + (i & 31);
@@ -1542,11 +1570,8 @@ __global__ __launch_bounds__(256) void f16x2_split_filter_if_changed_kernel(cons
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = atomicAdd(hdr + 5, 1u);
-        if (t == gridDim.x - 1) {
-            hdr[0] = amax; hdr[2] = (unsigned)sum; hdr[3] = (unsigned)(sum >> 32); hdr[4] = 1u;
-            hdr[5] = 0u;
-        }
+        if (!same) { hdr[0] = amax; hdr[2] = (unsigned)sum; hdr[3] = (unsigned)(sum >> 32); hdr[4] = 1u; }
+        hdr[5] = 0u;                                       // ticket back to zero for the next call
     }
 }
 
@@ -1692,14 +1717,10 @@ int f16x2_refresh_prepared(const float* w, void* prepared, int Cout, int K, hipS
     unsigned* part_max = hdr + 16;                                            // [256] words, then [256] 64-bit sums
     unsigned long long* part_sum = reinterpret_cast<unsigned long long*>(hdr + 16 + FP_PARTS);
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(prepared) + 64 + 4096);
-    long long blocks = (n + 2047) / 2048;
+    long long blocks = (n + 4095) / 4096;
     if (blocks < 1) blocks = 1;
     if (blocks > FP_PARTS) blocks = FP_PARTS;
-    hipLaunchKernelGGL(filter_fingerprint_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, n, part_max, part_sum);
-    Y4_CHECK_LAUNCH();
-    const int sb = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-    hipLaunchKernelGGL(f16x2_split_filter_if_changed_kernel, dim3(sb), dim3(256), 0, st, w, planes, n, part_max, part_sum,
-                       (int)blocks, hdr);
+    hipLaunchKernelGGL(f16x2_refresh_filter_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, planes, n, part_max, part_sum, hdr);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -215,10 +215,12 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const float* __restrict__ res, long long ldr, float* __restrict__ z, long long ldz,
-    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, int planes) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, int planes, float* __restrict__ twin) {
     // planes = 0: z fp32, max|z| folded into *out_amax.  z == nullptr: measure only (max|z| into *out_amax, nothing stored).
     // planes = 1: z receives the two fp16 pieces of the f16x2 split, per pixel and 32-channel K tile [64 B hi | 64 B lo]
-    //             (conv_planes.hip), scaled by the power of two that *out_amax -- measured by a previous launch -- implies.
+    //             (conv_planes.hip), scaled by the power of two that *out_amax -- a bound or a measured maximum -- implies.
+    // twin != nullptr (with planes = 1): z stays fp32 and `twin` receives the pre-split copy (a tensor with both a
+    //             plane-consuming conv and fp32 consumers).
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     unsigned amax = 0u;
@@ -252,9 +254,11 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
                     hi[e] = (_Float16)t;
                     lo[e] = (_Float16)((t - (float)hi[e]) * 2048.f);
                 }
-                unsigned char* row = reinterpret_cast<unsigned char*>(z + m * ldz) + (c0 >> 5) * 128 + (c0 & 31) * 2;
+                unsigned char* row = reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : z + m * ldz) +
+                                     (c0 >> 5) * 128 + (c0 & 31) * 2;
                 *reinterpret_cast<h4*>(row) = hi;
                 *reinterpret_cast<h4*>(row + 64) = lo;
+                if (twin) st4(z + m * ldz + c0, o);
             } else {
                 if (z) st4(z + m * ldz + c0, o);
                 amax_track(amax, o);
@@ -805,10 +809,12 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
-                      long long M, int C, unsigned* out_amax, int z_planes, const unsigned* res_amax, void* stream) {
+                      long long M, int C, unsigned* out_amax, int z_planes, const unsigned* res_amax, float* planes_twin,
+                      void* stream) {
     if (!y || !mean || !invstd || !gamma || !beta) return Y4_ERR_NULL;
     if (!z && (!out_amax || z_planes)) return Y4_ERR_NULL;                       // measure-only needs the word to fill
-    if (z_planes && (!out_amax || ldz != C || (C & 31))) return Y4_ERR_SHAPE;    // planes: dense rows, whole K tiles
+    if (planes_twin && (!z_planes || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
+    if (z_planes && (!out_amax || (!planes_twin && ldz != C) || (C & 31))) return Y4_ERR_SHAPE;   // planes: dense rows, whole K tiles
     if (z_planes == 2) {
         // the scale comes from an analytic bound of max|z| (no measuring pass); a residual must bring its own maximum
         if (residual && !res_amax) return Y4_ERR_NULL;
@@ -823,7 +829,7 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
                        (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
-                       M, C, rm.tpr, rm.rpb, out_amax, z_planes ? 1 : 0);
+                       M, C, rm.tpr, rm.rpb, out_amax, z_planes ? 1 : 0, planes_twin);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

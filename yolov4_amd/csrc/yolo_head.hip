@@ -47,6 +47,11 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(const float* __restric
     }
 }
 
+// sigmoid / exp of the tiled decode: v_exp_f32 + v_rcp_f32 (~1e-7 relative, far inside the 1e-4 parity bar) instead of
+// the IEEE expf + division sequences (30 VALU per element: at 185 M elements per bs = 32 batch the kernel was VALU-bound
+// at 2 TB/s whatever its access pattern)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+
 // Tiled form of the decode: a block takes DEC_TP consecutive pixels of ONE image with all their A * n_ch logit channels.
 //   phase 1: coalesced 16-B loads of whole pixel rows (a thread's four columns -- hence its anchor / channel roles -- are
 //            fixed for the whole tile: no division per element), activation applied on the way into an LDS image
@@ -80,22 +85,33 @@ __global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __r
         cch[e] = c < nt ? c - ca[e] * n_ch : 0;
     }
     const bool anyc = 4 * col4 < nt;
-    for (int r = r0; r < cnt; r += 4) {
+    // all of a thread's DEC_TP / 4 row loads go out before the first is used (the loop was latency-bound: one exposed
+    // HBM round trip per row)
+    f32x4 vv[DEC_TP / 4];
+#pragma unroll
+    for (int u = 0; u < DEC_TP / 4; ++u) {
+        const int r = r0 + 4 * u;
+        vv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (anyc && r < cnt) vv[u] = *reinterpret_cast<const f32x4*>(logits + ((long long)b * FF + p0 + r) * ldl + 4 * col4);
+    }
+#pragma unroll
+    for (int u = 0; u < DEC_TP / 4; ++u) {
+        const int r = r0 + 4 * u;
+        if (r >= cnt) break;
         const int pix = p0 + r;
         const int j = pix / F, i = pix - j * F;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (anyc) v = *reinterpret_cast<const f32x4*>(logits + ((long long)b * FF + pix) * ldl + 4 * col4);
+        const f32x4 v = vv[u];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int ch = cch[e], a = ca[e];
             float ov = v[e], pv = v[e];
             if (a >= 0) {
-                if (ch != 2 && ch != 3) { ov = sigmoidf_(v[e]); pv = ov; }
+                if (ch != 2 && ch != 3) { ov = fast_sigmoid(v[e]); pv = ov; }
                 if (ch == 0) pv = ov + (float)i;
                 else if (ch == 1) pv = ov + (float)j;
-                else if (ch == 2) pv = expf(v[e]) * anc.w[a];
-                else if (ch == 3) pv = expf(v[e]) * anc.h[a];
+                else if (ch == 2) pv = __expf(v[e]) * anc.w[a];
+                else if (ch == 3) pv = __expf(v[e]) * anc.h[a];
                 if (EVAL) { if (ch < 4) pv = pv * stride; }
                 else if (ch < 4) predt[a][r][ch] = pv;
             }
@@ -114,9 +130,12 @@ __global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __r
         const int head = mis ? 4 - mis : 0;                // scalar floats before the first aligned float4
         const int nv = len > head ? (len - head) >> 2 : 0;
         const int colbase = a * n_ch;
+        // (row, channel) of a thread's float4 advance by 1024 floats per trip: one division up front, none in the loop
+        const int adv_pl = 1024 / n_ch, adv_ch = 1024 - adv_pl * n_ch;
+        int pl0 = (head + 4 * tid) / n_ch, ch0 = head + 4 * tid - pl0 * n_ch;
         for (int q = tid; q < nv; q += 256) {
             const int o0 = head + 4 * q;
-            int pl = o0 / n_ch, ch = o0 - pl * n_ch;
+            int pl = pl0, ch = ch0;
             f32x4 w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -124,6 +143,8 @@ __global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __r
                 if (++ch == n_ch) { ch = 0; ++pl; }
             }
             *reinterpret_cast<f32x4*>(dst + o0) = w;
+            pl0 += adv_pl; ch0 += adv_ch;
+            if (ch0 >= n_ch) { ch0 -= n_ch; ++pl0; }
         }
         const int tail0 = head + 4 * nv;                   // scalar ends: [0, head) and [tail0, len)
         if (tid < head && tid < len) { const int pl = tid / n_ch; dst[tid] = tile[pl][colbase + tid - pl * n_ch]; }

@@ -53,13 +53,15 @@ class ConvBNAct(nn.Module):
         """out: optional destination (a CatBuffer slot) for the activation; dres_put / dres_take: the shared box through
         which a ResBlock unit's 3x3 conv hands the skip gradient to its 1x1 conv (see ResBlock); out_planes: the caller
         guarantees that the SOLE consumer of the result is a ConvBNAct for which `takes_planes()` holds, so the
-        activation may leave pre-split for the DMA-fed conv kernels (csrc/conv_planes.hip) instead of as fp32.  The
-        reference has none of these arguments."""
+        activation may leave pre-split for the DMA-fed conv kernels (csrc/conv_planes.hip) instead of as fp32;
+        out_planes='both': such a consumer exists beside fp32 ones -- the result is fp32 and carries a pre-split twin
+        (tensor attribute y4_twin, handed on by ops.fork).  The reference has none of these arguments."""
         n = self.norm
         io = {}
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
-               'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': bool(out_planes),
+               'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes,
+               'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self) else None,
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:
             use_batch_stats = self.training or n.running_mean is None
@@ -84,6 +86,8 @@ class ConvBNAct(nn.Module):
         z = ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
         if io.get('z_planes'):
             z.y4_planes = True                       # (tags do not survive autograd's output wrapping: set on the result)
+        if io.get('z_twin') is not None:
+            z.y4_twin = io['z_twin']
         return ops.tag_amax(z, io.get('z_amax'))
 
 
@@ -99,13 +103,15 @@ def takes_planes(m):
     return ops.PLANES['on'] and ops.f16x2_mode() and m.conv.weight.is_cuda
 
 
-def chain(seq, x):
+def chain(seq, x, last=False):
     """nn.Sequential of ConvBNAct layers, each feeding only the next: intermediates leave pre-split where the consumer
-    can take them (same results as seq(x); the reference calls the Sequential)."""
+    can take them (same results as seq(x); the reference calls the Sequential).  last: out_planes of the final layer
+    (True: its sole consumer takes planes; 'both': one of several does)."""
     mods = list(seq)
     for i, m in enumerate(mods):
         nxt = mods[i + 1] if i + 1 < len(mods) else None
-        x = m(x, out_planes=nxt is not None and takes_planes(nxt)) if isinstance(m, ConvBNAct) else m(x)
+        want = takes_planes(nxt) if nxt is not None else last
+        x = m(x, out_planes=want) if isinstance(m, ConvBNAct) else m(x)
     return x
 
 

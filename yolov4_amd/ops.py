@@ -491,21 +491,27 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
         residual, ldr = as_nhwc(residual)
     if planes:
         cell = planes_cell(y.device)
-        z = empty_nhwc(B, C, H, W, y.device)
+        both = planes == 'both'
+        zp = empty_nhwc(B, C, H, W, y.device)        # the pre-split tensor (float32-typed, 4 bytes per element)
+        z = (out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)) if both else zp
         args = (_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act], _ptr(residual), ldr)
         res_cell = amax_of(residual) if residual is not None else None
         if residual is not None and res_cell is None:
-            check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), 0, None, _stream()), 'bn_act_fwd(measure)')
+            check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), 0, None, None, _stream()), 'bn_act_fwd(measure)')
             mode = 1
         else:
             mode = 2
-        check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), mode, _ptr(res_cell), _stream()),
-              'bn_act_fwd(planes)')
-        z.y4_planes = True
-        return tag_amax(z, cell)
+        check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), mode, _ptr(res_cell),
+                                  _ptr(zp) if both else None, _stream()), 'bn_act_fwd(planes)')
+        zp.y4_planes = True
+        tag_amax(zp, cell)
+        if both:
+            z.y4_twin = zp                           # fp32 for everybody else, planes for the conv that can take them
+        return tag_amax(z, cell[0:1])
     z = out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)
     check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act],
-                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), 0, None, _stream()), 'bn_act_fwd')
+                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), 0, None, None, _stream()),
+          'bn_act_fwd')
     return z
 
 
@@ -651,6 +657,8 @@ class ConvBNActFn(torch.autograd.Function):
         # pre-split operands (conv_planes.hip): x arrives as planes when its producer was asked to (out_planes, below);
         # all three of this layer's convs then run on the DMA kernels, dy leaving the BatchNorm backward as planes too
         xp = planes_of(x)
+        if xp is None and cfg.get('x_twin') is not None:
+            xp = planes_of(cfg['x_twin'])            # x itself is fp32 (it has other consumers); its pre-split twin feeds this conv
         ctx.x_planes = xp is not None
         if xp is not None and not (f16 and bn and training and s == 1 and weight.shape[0] % 32 == 0 and x.shape[1] % 32 == 0):
             raise Y4Error('a pre-split (planes) tensor reached a conv that cannot consume it')
@@ -671,18 +679,21 @@ class ConvBNActFn(torch.autograd.Function):
             else:
                 y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
                                                        cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax)
-            if cfg.get('out_planes') and f16 and dest is None and y.shape[1] % 32 == 0:
-                z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, planes=True)
+            want = cfg.get('out_planes')
+            if want and f16 and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
+                z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest if want == 'both' else None,
+                                   planes='both' if want == 'both' else True)
                 z_amax = z.y4_amax
                 if io is not None:
-                    io['z_planes'] = True
+                    io['z_planes'] = want != 'both'
+                    io['z_twin'] = getattr(z, 'y4_twin', None)
             else:
                 if f16x2_mode():
                     z_amax = live(cfg.get('out_amax')) if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
                     if z_amax is None:
                         z_amax = new_amax(x.device)
                 z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
-            ctx.save_for_backward(x, weight, y, mean, invstd, gamma, beta)
+            ctx.save_for_backward(xp.buf if xp is not None else x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
         elif bn:
             # no autograd in flight (val.py / detect.py): the filter planes and the BN fold are per-parameter-version caches
@@ -819,6 +830,9 @@ def fork(x):
         return x, x
     a, b = Fork2Fn.apply(x)
     cell = amax_of(x)
+    twin = getattr(x, 'y4_twin', None)
+    if twin is not None:
+        a.y4_twin = b.y4_twin = twin
     return tag_amax(a, cell), tag_amax(b, cell)
 
 

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from ... import ops
-from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain
+from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain, takes_planes
 from .yololayer import YOLOLayer
 
 L = 'leaky_relu'
@@ -56,8 +56,9 @@ class SPPBlock(nn.Module):
         self.max_pool3 = nn.MaxPool2d(13, 1, 13 // 2)
         self.conv2 = ConvBNAct(2048, 512, 1, 1, act=L)
 
-    def forward(self, x):
-        return self.conv2(ops.spp_pool_cat(chain(self.conv1, x)))
+    def forward(self, x, out_planes=False):
+        """out_planes: the sole consumer (fpn.module1[0]) takes a pre-split input; the reference has no such argument."""
+        return self.conv2(ops.spp_pool_cat(chain(self.conv1, x)), out_planes=out_planes)
 
 
 class Upsample(nn.Module):
@@ -102,7 +103,8 @@ class FPNBlock(nn.Module):
         self.conv11 = ConvBNAct(256, 128, 1, 1, act=L)
         self.module3 = _five(256, 128)
 
-    def forward(self, x3, x4, x5):
+    def forward(self, x3, x4, x5, head_planes=False):
+        """head_planes: head.yolo1[0] (one of the two consumers of f1) takes a pre-split input."""
         f3 = chain(self.module1, x5)
         f3a, f3b = ops.fork(f3)
         cb = ops.cat_buffer(x4, [256, 256])                      # [conv4(x4) | upsampled conv3(f3)], written in place
@@ -115,7 +117,7 @@ class FPNBlock(nn.Module):
         up = self.upsample2(self.conv10(f2a), x3.size(), out=cb.slot(1))
         x3 = self.conv11(x3, out=cb.slot(0))
         assert up.shape[2:] == x3.shape[2:]
-        f1 = chain(self.module3, ops.cat([x3, up], into=cb))
+        f1 = chain(self.module3, ops.cat([x3, up], into=cb), last='both' if head_planes else False)
         return f1, f2b, f3b
 
 
@@ -128,17 +130,18 @@ class PANBlock(nn.Module):
         self.conv7 = ConvBNAct(256, 512, 3, 2, act=L)
         self.module2 = _five(1024, 512)
 
-    def forward(self, f1, f2, f3):
+    def forward(self, f1, f2, f3, head_planes=(False, False)):
+        """head_planes: head.yolo2[0] / head.yolo3[0] take a pre-split input (p2 has a second, fp32 consumer; p3 none)."""
         p1, f1b = ops.fork(f1)
         cb = ops.cat_buffer(f2, [256, f2.shape[1]])
         p2 = self.conv1(f1b, out=cb.slot(0))
         assert p2.shape[2:] == f2.shape[2:]
-        p2 = chain(self.module1, ops.cat([p2, f2], into=cb))
+        p2 = chain(self.module1, ops.cat([p2, f2], into=cb), last='both' if head_planes[0] else False)
         p2a, p2b = ops.fork(p2)
         cb = ops.cat_buffer(f3, [512, f3.shape[1]])
         p3 = self.conv7(p2a, out=cb.slot(0))
         assert p3.shape[2:] == f3.shape[2:]
-        p3 = chain(self.module2, ops.cat([p3, f3], into=cb))
+        p3 = chain(self.module2, ops.cat([p3, f3], into=cb), last=bool(head_planes[1]))
         return p1, p2b, p3
 
 
@@ -150,8 +153,10 @@ class Neck(nn.Module):
         self.fpn = FPNBlock()
         self.pan = PANBlock()
 
-    def forward(self, x3, x4, x5):
-        return self.pan(*self.fpn(x3, x4, self.spp(x5)))
+    def forward(self, x3, x4, x5, head_planes=(False, False, False)):
+        """head_planes: which of the three head 3x3 convs take pre-split inputs (YOLOv4.forward asks them)."""
+        x5 = self.spp(x5, out_planes=takes_planes(self.fpn.module1[0]))
+        return self.pan(*self.fpn(x3, x4, x5, head_planes=head_planes[0]), head_planes=head_planes[1:])
 
 
 class Head(nn.Module):
@@ -206,7 +211,8 @@ class YOLOv4(nn.Module):
     def forward(self, x):
         if x.dtype != torch.float32:
             x = x.float()              # Transform hands float64 images; apex O0 casts them
-        p1, p2, p3 = self.neck(*self.backbone(x))
+        hp = tuple(takes_planes(h[0]) for h in (self.head.yolo1, self.head.yolo2, self.head.yolo3))
+        p1, p2, p3 = self.neck(*self.backbone(x), head_planes=hp)
         if self.training:
             return list(self.head(p1, p2, p3))
         # eval: the three decodes write into one [B, N, 5+C] buffer (the cat of yolov4.py:324, no copy)
