@@ -368,6 +368,13 @@ def infer_main(args):
     dec_bytes = 2.0 * B * N * 85 * 4
     cnt_bytes = 1.0 * B * N * 85 * 4 + B * N * 4 * 4        # reads every score once, rewrites the 4 box columns (xyxy)
     surv = sum(0 if d is None else len(d) for d in det) / B
+    # the three decode launches of a batch in call order: F = S/8, S/16, S/32
+    per_layer = {}
+    for li, F_ in enumerate((S // 8, S // 16, S // 32)):
+        evs = rec['decode'][li::3]
+        t_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(len(evs), 1)
+        by = 2.0 * B * 3 * F_ * F_ * 85 * 4
+        per_layer[f'F={F_}'] = {'ms': t_ms, 'GB/s': by / (t_ms * 1e-3) / 1e9, 'algorithmic_bytes': by}
     outj = {'metric': f'images/sec inference @{S}x{S} bs={B} (eval forward + YOLO decode + postprocess / per-class NMS)',
             'value': B * args.steps / dt, 'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -378,16 +385,17 @@ def infer_main(args):
                        'forward_ms': tf / args.steps * 1e3, 'postprocess_ms': tp / args.steps * 1e3,
                        'forward_images_per_sec': B * args.steps / tf,
                        'forward_conv_tflops': B * args.steps / tf * 134.422e9 * (S / 608.0) ** 2 / 1e12},
-            'roofline': {'bound': 'hbm', 'kernel': 'yolo_decode_kernel<true> (3 launches per batch)',
+            'roofline': {'bound': 'hbm', 'kernel': 'yolo_decode_tiled_kernel<true, 32 | 16> (3 launches per batch)',
                          'achieved': dec_bytes / (ms('decode') * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': dec_bytes / (ms('decode') * 1e-3) / 1e9 / 8000.0, 'traffic': None,
                          'algorithmic_bytes_per_batch': dec_bytes, 'ms_per_batch': ms('decode'),
                          'measured': 'LIVE: HIP events around the three decode launches of every timed batch',
+                         'per_layer': per_layer,
                          'other_kernels': {
-                             'post_count_kernel (xywh->xyxy + candidate count)': {
+                             'post_count_tiled_kernel (xywh->xyxy + candidate count)': {
                                  'ms_per_batch': ms('post_count'), 'GB/s': cnt_bytes / (ms('post_count') * 1e-3) / 1e9,
                                  'algorithmic_bytes_per_batch': cnt_bytes},
-                             'post_fill + segment sort + post_nms (data dependent)': {
+                             'post_scan + post_fill + segment sort + post_nms (data dependent)': {
                                  'ms_per_batch': ms('post_fill_sort_nms'), 'candidates_per_img_target': 500,
                                  'survivors_per_img': surv}}}}
     print(json.dumps(outj))

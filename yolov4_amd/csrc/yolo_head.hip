@@ -5,6 +5,7 @@
 // This file is compiled with -ffp-contract=off: IoU comparisons against thresholds must follow
 // the reference's separate fp32 multiply / add / divide sequence bit for bit
 // (yolo/model/yololoss.py:56-91, yolo/util/utils.py:64-77).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -47,11 +48,6 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(const float* __restric
     }
 }
 
-// sigmoid / exp of the tiled decode: v_exp_f32 + v_rcp_f32 (~1e-7 relative, far inside the 1e-4 parity bar) instead of
-// the IEEE expf + division sequences (30 VALU per element: at 185 M elements per bs = 32 batch the kernel was VALU-bound
-// at 2 TB/s whatever its access pattern)
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-
 // Tiled form of the decode: a block takes DEC_TP consecutive pixels of ONE image with all their A * n_ch logit channels.
 //   phase 1: coalesced 16-B loads of whole pixel rows (a thread's four columns -- hence its anchor / channel roles -- are
 //            fixed for the whole tile: no division per element), activation applied on the way into an LDS image
@@ -60,9 +56,10 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f +
 //            floats of consecutive pixels follow each other in [B, N, n_ch] / [B, A, F, F, n_ch]): written with aligned
 //            16-B stores gathered from the LDS image (scalar stores for the <= 3 floats at either end of the run).
 // The per-channel kernel above read 4 bytes per lane with a 1-KiB stride between lanes' pixels and wrote three 340-B
-// segments per pixel (0.22 of the HBM peak); this one moves whole lines both ways.
-constexpr int DEC_TP = 32;                                 // pixels per tile: 32 x 256 floats = 32 KiB of LDS
-template <bool EVAL>
+// segments per pixel (0.22 of the HBM peak) and spent 30 VALU per element on IEEE expf + division; this one moves whole
+// lines both ways with one v_exp_f32 + one v_rcp_f32 per element (~1e-7 relative, far inside the 1e-4 parity bar):
+// 4.6 - 4.9 TB/s algorithmic on the 76 x 76 layer at bs = 32 (rows of 32 pixels; 16 on small maps for occupancy).
+template <bool EVAL, int DEC_TP>                           // DEC_TP pixels per tile: DEC_TP x 256 floats of LDS
 __global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __restrict__ logits, long long ldl,
                                                                 float* __restrict__ output, float* __restrict__ pred,
                                                                 long long n_total, long long box_off, float stride,
@@ -75,18 +72,26 @@ __global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __r
     const int p0 = t * DEC_TP;
     const int cnt = FF - p0 < DEC_TP ? FF - p0 : DEC_TP;
     const int nt = A * n_ch;
-    // ---- phase 1
+    // ---- phase 1.  Per column (fixed for the thread): value = rcp(exp(-v) + one) * mul + (ci * i + cj * j)
+    //   sigmoid channels: one = 1 (1 / (1 + e^-v)); exp channels (w, h): one = 0 (1 / e^-v = e^v), mul = anchor (* stride)
+    // -> one v_exp, one v_rcp and three plain VALU per element, no per-element role tests
     const int col4 = tid & 63, r0 = tid >> 6;
+    f32x4 one, mul, ci, cj;
     int ca[4], cch[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int c = 4 * col4 + e;
-        ca[e] = c < nt ? c / n_ch : -1;
-        cch[e] = c < nt ? c - ca[e] * n_ch : 0;
+        const int a = c < nt ? c / n_ch : -1;
+        const int ch = c < nt ? c - a * n_ch : 4;
+        ca[e] = a; cch[e] = ch;
+        const float sc = (EVAL && ch < 4) ? stride : 1.0f;
+        one[e] = (ch == 2 || ch == 3) ? 0.f : 1.f;
+        mul[e] = ch == 2 ? anc.w[a < 0 ? 0 : a] * sc : ch == 3 ? anc.h[a < 0 ? 0 : a] * sc : sc;
+        ci[e] = ch == 0 ? sc : 0.f;
+        cj[e] = ch == 1 ? sc : 0.f;
     }
     const bool anyc = 4 * col4 < nt;
-    // all of a thread's DEC_TP / 4 row loads go out before the first is used (the loop was latency-bound: one exposed
-    // HBM round trip per row)
+    // all of a thread's DEC_TP / 4 row loads go out before the first is used (the loop was latency-bound otherwise)
     f32x4 vv[DEC_TP / 4];
 #pragma unroll
     for (int u = 0; u < DEC_TP / 4; ++u) {
@@ -100,22 +105,21 @@ __global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __r
         if (r >= cnt) break;
         const int pix = p0 + r;
         const int j = pix / F, i = pix - j * F;
+        const float fi = (float)i, fj = (float)j;
         const f32x4 v = vv[u];
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int ch = cch[e], a = ca[e];
-            float ov = v[e], pv = v[e];
-            if (a >= 0) {
-                if (ch != 2 && ch != 3) { ov = fast_sigmoid(v[e]); pv = ov; }
-                if (ch == 0) pv = ov + (float)i;
-                else if (ch == 1) pv = ov + (float)j;
-                else if (ch == 2) pv = __expf(v[e]) * anc.w[a];
-                else if (ch == 3) pv = __expf(v[e]) * anc.h[a];
-                if (EVAL) { if (ch < 4) pv = pv * stride; }
-                else if (ch < 4) predt[a][r][ch] = pv;
+            const float t = __expf(-v[e]);
+            const float rr = __frcp_rn(t + one[e]);
+            const float pv = rr * mul[e] + (ci[e] * fi + cj[e] * fj);
+            if (EVAL) {
+                o[e] = pv;
+            } else {
+                const int ch = cch[e];
+                o[e] = (ch == 2 || ch == 3) ? v[e] : rr;          // `output` keeps the raw w / h logits (yololayer.py:136-139)
+                if (ca[e] >= 0 && ch < 4) predt[ca[e]][r][ch] = pv;
             }
-            o[e] = EVAL ? pv : ov;
         }
         *reinterpret_cast<f32x4*>(&tile[r][4 * col4]) = o;
     }
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(256) void yolo_decode_tiled_kernel(const float* __r
     }
 }
 
+static int decode_tp(long long npix) { return npix >= 100000 ? 32 : 16; }      // tile height: measured best per map size
 static bool decode_tiled_ok(const float* logits, int ldl, int A, int n_ch, const float* output, const float* pred) {
     return A * n_ch <= 256 && A <= 4 && (ldl & 3) == 0 && ldl >= ((A * n_ch + 3) & ~3) &&
            (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(output) & 3) == 0 &&
@@ -1031,9 +1036,11 @@ int y4_yolo_decode_train_f32(const float* logits, int ldl, float* output, float*
     if (B <= 0 || F <= 0 || A <= 0 || n_classes <= 0 || ldl < A * n_ch || !fill_anchors(anc, anchors_wh_host, A))
         return Y4_ERR_SHAPE;
     const long long npix = (long long)B * F * F;
-    const long long tpi = ((long long)F * F + DEC_TP - 1) / DEC_TP;
+    const int tp = decode_tp(npix);
+    const long long tpi = ((long long)F * F + tp - 1) / tp;
     if (decode_tiled_ok(logits, ldl, A, n_ch, output, pred) && (long long)B * tpi < (1ll << 31)) {
-        hipLaunchKernelGGL(yolo_decode_tiled_kernel<false>, dim3((unsigned)(B * tpi)), dim3(256), 0, y4_stream(stream), logits,
+        auto kern = tp == 16 ? yolo_decode_tiled_kernel<false, 16> : yolo_decode_tiled_kernel<false, 32>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * tpi)), dim3(256), 0, y4_stream(stream), logits,
                            (long long)ldl, output, pred, 0ll, 0ll, 1.0f, F, A, n_ch, anc, (int)tpi);
         Y4_CHECK_LAUNCH();
         return Y4_OK;
@@ -1054,9 +1061,11 @@ int y4_yolo_decode_eval_f32(const float* logits, int ldl, float* out, long long 
         return Y4_ERR_SHAPE;
     if (box_off < 0 || box_off + (long long)A * F * F > n_total) return Y4_ERR_SHAPE;
     const long long npix = (long long)B * F * F;
-    const long long tpi = ((long long)F * F + DEC_TP - 1) / DEC_TP;
+    const int tp = decode_tp(npix);
+    const long long tpi = ((long long)F * F + tp - 1) / tp;
     if (decode_tiled_ok(logits, ldl, A, n_ch, out, nullptr) && (long long)B * tpi < (1ll << 31)) {
-        hipLaunchKernelGGL(yolo_decode_tiled_kernel<true>, dim3((unsigned)(B * tpi)), dim3(256), 0, y4_stream(stream), logits,
+        auto kern = tp == 16 ? yolo_decode_tiled_kernel<true, 16> : yolo_decode_tiled_kernel<true, 32>;
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * tpi)), dim3(256), 0, y4_stream(stream), logits,
                            (long long)ldl, out, (float*)nullptr, n_total, box_off, stride, F, A, n_ch, anc, (int)tpi);
         Y4_CHECK_LAUNCH();
         return Y4_OK;
