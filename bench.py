@@ -450,10 +450,16 @@ def main():
     x = torch.randn((B, 3, S, S), generator=g).to(dev)
     labels = recipe.synth_labels(B, S, 2000 + rank).to(dev)
 
+    from yolov4_amd import trace
+
     def step():
         ddp.zero_grad()
-        loss = crit(ddp(x), {'padded_labels': labels})
-        loss.backward()                                  # the exchange is waited for by BucketedDDP's end-of-backward callback
+        with trace.range('y4.forward'):                  # roctx ranges with Y4_ROCTX=1 (no-ops otherwise)
+            out_ = ddp(x)
+        with trace.range('y4.loss'):
+            loss = crit(out_, {'padded_labels': labels})
+        with trace.range('y4.backward'):
+            loss.backward()                              # the exchange is waited for by BucketedDDP's end-of-backward callback
         return loss
 
     for _ in range(args.warmup):

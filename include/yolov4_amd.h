@@ -155,6 +155,21 @@ int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, floa
                                void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
                                void* stream);
 
+/* Any other ConvBNAct shape (darknet/darknet.py:25-36 takes any in_ch / out_ch / odd kernel_size / stride): direct kernels,
+ * one thread per output element, plain fp32 fma chains -- written for correctness, YOLOv4 never builds such a layer.
+ * Same NHWC / KRSC conventions and epilogue (scale, shift, act, residual) as y4_conv2d_fwd_f32; pad = (k - 1) / 2.
+ * y4_conv2d_stem_dgrad_f32: gradient wrt the 3-channel network input (element strides as y4_conv2d_stem_fwd_f32). */
+int y4_conv2d_generic_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy,
+                              int B, int H, int W, int Cin, int Cout, int k, int stride,
+                              const float* scale, const float* shift, int act, const float* residual, int ldr, void* stream);
+int y4_conv2d_generic_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+                                int B, int H, int W, int Cin, int Cout, int k, int stride,
+                                const float* residual, int ldr, void* stream);
+int y4_conv2d_generic_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
+                                int B, int H, int W, int Cin, int Cout, int k, int stride, void* stream);
+int y4_conv2d_stem_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, long long sxb, long long sxc, long long sxh,
+                             long long sxw, int B, int H, int W, int Cout, void* stream);
+
 /* Stem conv (Cin = 3): x addressed as x[b*sxb + c*sxc + h*sxh + w*sxw] so both the NCHW
  * tensor the reference feeds (yolo/engine/build.py:60) and NHWC work without a copy.
  * bnstats_partials (nullable): [ceil(B*H*W/256)][2][Cout] column sums of the output, valid when
@@ -238,6 +253,8 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                          plane conv kernels (layout as y4_bn_act_fwd_f32 z_planes; lddy == C, C % 32 == 0), scaled by a
                          bound of max|dy| derived before the sweep; word [5] receives that bound and serves as dy_amax
                          of y4_conv2d_dgrad_planes_f32 / y4_conv2d_wgrad_planes_f32 */,
+                      int frozen_stats /* != 0: mean / invstd are constants (eval-mode BatchNorm under autograd: running
+                         statistics), so dy = gamma invstd g without the two batch-statistic terms; dgamma / dbeta as usual */,
                       void* stream);
 /* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249): two fixed-order stages, no atomics
  * (deterministic).  workspace: y4_bias_grad_workspace(M, C) bytes */

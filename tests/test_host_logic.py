@@ -277,3 +277,33 @@ def test_build_optimizer_sgd_branch_and_no_detached_grads():
     opt = build_optimizer(cfg, m)
     assert isinstance(opt, FusedSGD) and opt.defaults['momentum'] == 0.9 and opt.defaults['weight_decay'] == 1e-5
     assert opt.param_groups[1]['weight_decay'] == 0.
+
+
+def test_roctx_ranges_are_noops_unless_enabled(monkeypatch):
+    """yolov4_amd.trace: with Y4_ROCTX unset the ranges do nothing and no library is loaded; with Y4_ROCTX=1 they call
+    roctxRangePushA / roctxRangePop of libroctx64.so (present in the ROCm image) in matched pairs."""
+    from yolov4_amd import trace
+    monkeypatch.delenv('Y4_ROCTX', raising=False)
+    trace._STATE.update(lib=None, tried=False)
+    with trace.range('x'):
+        pass
+    assert trace._STATE['tried'] is False
+    monkeypatch.setenv('Y4_ROCTX', '1')
+    calls = []
+
+    class Fake:
+        def roctxRangePushA(self, name):
+            calls.append(('push', name))
+            return 0
+
+        def roctxRangePop(self):
+            calls.append(('pop', None))
+            return 0
+    trace._STATE.update(lib=Fake(), tried=True)
+    try:
+        with trace.range('y4.forward'):
+            with trace.range('inner'):
+                pass
+    finally:
+        trace._STATE.update(lib=None, tried=False)
+    assert calls == [('push', b'y4.forward'), ('push', b'inner'), ('pop', None), ('pop', None)]

@@ -391,10 +391,10 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const double* __restrict__ acc, float* __restrict__ dy, long long lddy,
-    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds, int frozen) {
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
-    const double invM = 1.0 / (double)M;
+    const double invM = frozen ? 0.0 : 1.0 / (double)M;    // frozen statistics: no batch-statistic terms in dy
     unsigned amax = 0u;
     // plane output (conv mode 3): dy leaves as the two fp16 pieces the conv kernels would otherwise split it into,
     // per pixel and 32-channel K tile [64 B hi | 64 B scaled lo] in the 4C bytes of the fp32 row.  The scale needs max|dy| BEFORE the
@@ -838,8 +838,9 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            int act, float* dy, int lddy, float* dgamma, float* dbeta,
                            long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                           unsigned* f16_planes, void* stream) {
+                           unsigned* f16_planes, int frozen, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
+    if (frozen && f16_planes) return Y4_ERR_SHAPE;         // (the plane bound is derived for batch statistics)
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
@@ -865,7 +866,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
                        (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,
-                       out_amax, f16_planes);
+                       out_amax, f16_planes, frozen ? 1 : 0);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -874,9 +875,9 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,
                       long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                      unsigned* f16_planes, void* stream) {
+                      unsigned* f16_planes, int frozen_stats, void* stream) {
     return bn_act_bwd_impl(dz, lddz, y, ldy, mean, invstd, gamma, beta, act, dy, lddy, dgamma, dbeta, M, C, workspace,
-                           workspace_bytes, out_amax, f16_planes, stream);
+                           workspace_bytes, out_amax, f16_planes, frozen_stats, stream);
 }
 
 static int colsum_rows(long long M) { return (int)(M < 1024 ? M : 1024); }

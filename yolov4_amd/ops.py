@@ -215,6 +215,12 @@ def prepared_filter(param):
     return buf
 
 
+def fast_conv_shape(Cin, k, s):
+    """Shapes the implicit-GEMM kernels take (everything YOLOv4 builds); anything else ConvBNAct accepts -- any channel
+    count, odd kernel size, stride -- runs on the direct kernels of csrc/conv_generic.hip."""
+    return k in (1, 3) and s in (1, 2) and (Cin % 32 == 0 or (Cin == 3 and k == 3 and s == 1))
+
+
 def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
                  out_amax=None, w_prepared=None):
     L = lib()
@@ -225,6 +231,16 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
         out = empty_nhwc(B, Cout, Ho, Wo, x.device, pad_to=out_pad)
     ldy = nhwc_pitch(out)
     w = krsc(w)
+    if not fast_conv_shape(Cin, k, s) or (Cin == 3 and (Cout > 32 or residual is not None)):
+        if k % 2 == 0:
+            raise Y4Error('even kernel sizes are not supported (pad = (k - 1) // 2 would not keep the map size)')
+        x, ldx = as_nhwc(x, need_vec4=False)
+        ldr = 0
+        if residual is not None:
+            residual, ldr = as_nhwc(residual, need_vec4=False)
+        check(L.y4_conv2d_generic_fwd_f32(_ptr(x), ldx, _ptr(w), _ptr(out), ldy, B, H, W, Cin, Cout, k, s, _ptr(scale), _ptr(shift),
+                                          ACT_IDS[act], _ptr(residual), ldr, _stream()), 'conv2d_generic_fwd')
+        return out
     if Cin == 3:
         if k != 3 or s != 1 or residual is not None:
             raise Y4Error('Cin=3 is supported for the 3x3/s1 stem only')
@@ -256,6 +272,13 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
     Ho, Wo = conv_out_hw(H, W, k, s)
+    if not fast_conv_shape(Cin, k, s) or (Cin == 3 and Cout > 32) or Cout % 4:
+        # direct conv, statistics by a sweep over its output (y4_bn_stats_f32 needs 16-B rows: pitch rounded up to 4)
+        if Cout % 4:
+            raise Y4Error('BatchNorm over a channel count that is not a multiple of 4 is not supported')
+        y = conv_fwd_raw(x, w, k, s, out=empty_nhwc(B, Cout, Ho, Wo, x.device, pad_to=4), x_amax=x_amax)
+        mean, invstd = bn_stats_raw(y, running_mean, running_var, nbt, momentum, eps)
+        return y, mean, invstd
     y = empty_nhwc(B, Cout, Ho, Wo, x.device)
     ldy = nhwc_pitch(y)
     w = krsc(w)
@@ -387,6 +410,18 @@ def conv_wgrad_planes_raw(xp, dyp, w_shape, k, out=None):
     return dw
 
 
+def conv_stem_dgrad_raw(dy, w, x):
+    """Gradient wrt the 3-channel network input (same shape and strides as x)."""
+    L = lib()
+    B, _, H, W = x.shape
+    dy, lddy = as_nhwc(dy, need_vec4=False)
+    dx = torch.empty_like(x, memory_format=torch.preserve_format)
+    sb, sc, sh, sw = dx.stride()
+    check(L.y4_conv2d_stem_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), sb, sc, sh, sw, B, H, W, w.shape[0], _stream()),
+          'conv2d_stem_dgrad')
+    return dx
+
+
 def last_conv_kernel():
     """Symbol (as rocprofv3 prints it) of the conv kernel this thread launched last, '' if unknown; measurement aid."""
     import ctypes
@@ -399,6 +434,15 @@ def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None):
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
+    if k not in (1, 3) or s not in (1, 2):
+        dy, lddy = as_nhwc(dy, need_vec4=False)
+        dx = empty_nhwc(B, Cin, H, W, dy.device)
+        ldr = 0
+        if residual is not None:
+            residual, ldr = as_nhwc(residual, need_vec4=False)
+        check(L.y4_conv2d_generic_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
+                                            _ptr(residual), ldr, _stream()), 'conv2d_generic_dgrad')
+        return dx
     cpad = (Cout + 31) // 32 * 32
     dy, lddy = as_nhwc(dy, min_pitch=cpad)
     dx = empty_nhwc(B, Cin, H, W, dy.device)
@@ -439,6 +483,12 @@ def conv_wgrad_raw(x, dy, w_shape, k, s, out=None, x_amax=None, dy_amax=None):
         WGRAD_STATS['temporary'] += 1
         dw = torch.empty(w_shape, device=dy.device, dtype=torch.float32).contiguous(memory_format=CL)
         dw = krsc(dw)
+    if k not in (1, 3) or s not in (1, 2) or (Cin % 4 and Cin != 3) or (Cin == 3 and (k != 3 or s != 1 or Cout > 32)):
+        xs, ldx = as_nhwc(x, need_vec4=False)
+        dys, lddy = as_nhwc(dy, need_vec4=False)
+        check(L.y4_conv2d_generic_wgrad_f32(_ptr(xs), ldx, _ptr(dys), lddy, _ptr(dw), B, H, W, Cin, Cout, k, s, _stream()),
+              'conv2d_generic_wgrad')
+        return dw
     if Cin == 3:
         dy, lddy = as_nhwc(dy, need_vec4=False)
         nbytes = L.y4_conv2d_stem_wgrad_workspace(B, H, W, Cout)
@@ -515,7 +565,8 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
     return z
 
 
-def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None):
+def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None,
+                   frozen=False):
     """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
     L = lib()
     B, C, H, W = y.shape
@@ -531,7 +582,7 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
-                              _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), _stream()), 'bn_act_bwd')
+                              _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), 1 if frozen else 0, _stream()), 'bn_act_bwd')
     return dy, dgamma, dbeta
 
 
@@ -607,14 +658,15 @@ def join_side_stream(device=None):
     _ASYNC['join_queued'] = False
 
 
-def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None):
-    """wgrad on the side stream, accumulated straight into param.grad (autograd gets None for this input)."""
+def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None, fn=None):
+    """wgrad on the side stream, accumulated straight into param.grad (autograd gets None for this input).  fn: the wgrad
+    call to make there (default: the register-staged kernel on fp32 operands)."""
     main = torch.cuda.current_stream(x.device)
     side = side_stream(x.device)
     ev = main.record_event()
     with torch.cuda.stream(side):
         side.wait_event(ev)
-        dw = conv_wgrad_raw(x, dy, tuple(param.shape), k, s, x_amax=x_amax, dy_amax=dy_amax)
+        dw = fn() if fn is not None else conv_wgrad_raw(x, dy, tuple(param.shape), k, s, x_amax=x_amax, dy_amax=dy_amax)
         if param.grad is None:
             dw.record_stream(main)          # allocated in the side stream's pool, consumed (and freed) on the main one
             param.grad = dw
@@ -695,6 +747,20 @@ class ConvBNActFn(torch.autograd.Function):
                 z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
             ctx.save_for_backward(xp.buf if xp is not None else x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
+        elif bn and cfg.get('grad', True) and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
+            # eval-mode BatchNorm UNDER autograd (frozen statistics, e.g. fine-tuning): the unfused sequence, so that
+            # backward has the pre-BN tensor; running statistics play mean / invstd and receive no batch terms
+            y = conv_fwd_raw(x, weight, k, s, x_amax=x_amax, out=empty_nhwc(x.shape[0], weight.shape[0],
+                                                                              *conv_out_hw(x.shape[2], x.shape[3], k, s), x.device, pad_to=4))
+            invstd, _ = bn_fold_raw(torch.ones_like(gamma), beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
+            mean = cfg['running_mean']
+            if f16x2_mode():
+                z_amax = live(cfg.get('out_amax')) if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
+                if z_amax is None:
+                    z_amax = new_amax(x.device)
+            z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
+            ctx.save_for_backward(x, weight, y, mean.detach().clone(), invstd, gamma, beta)
+            ctx.mode = 'bn_eval_grad'
         elif bn:
             # no autograd in flight (val.py / detect.py): the filter planes and the BN fold are per-parameter-version caches
             frozen = not cfg.get('grad', True) and os.environ.get('Y4_NO_INFER_CACHE') != '1'
@@ -731,7 +797,7 @@ class ConvBNActFn(torch.autograd.Function):
         dy_amax = None
         x_amax = live(ctx.x_amax)                     # None if the ring recycled it since forward: wgrad takes its own pass
         x_planes = getattr(ctx, 'x_planes', False)
-        if ctx.mode == 'bn_train':
+        if ctx.mode in ('bn_train', 'bn_eval_grad'):
             x, weight, y, mean, invstd, gamma, beta = ctx.saved_tensors
             gp, bp = cfg.get('gamma_param'), cfg.get('beta_param')
             sink = (gp is not None and bp is not None and getattr(gp, '_y4_grad_fresh', False)
@@ -743,7 +809,8 @@ class ConvBNActFn(torch.autograd.Function):
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                                gp.grad if sink else None, bp.grad if sink else None,
-                                               out_amax=None if planes is not None else dy_amax, planes=planes)
+                                               out_amax=None if planes is not None else dy_amax, planes=planes,
+                                               frozen=ctx.mode == 'bn_eval_grad')
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
                 gp._y4_grad_fresh = bp._y4_grad_fresh = False
@@ -759,17 +826,16 @@ class ConvBNActFn(torch.autograd.Function):
             if f16:
                 dy_amax = amax_raw(dy)               # used by dgrad and wgrad: one pass instead of two
         else:
-            raise Y4Error(f'backward through ConvBNAct in mode {ctx.mode} is not implemented '
-                          '(the reference trains in train mode only, yolo/engine/build.py:45)')
+            raise Y4Error(f'backward through ConvBNAct in mode {ctx.mode} is not implemented')
         dx = None
         take = cfg.get('dres_take')
         skip_grad = take.pop('dres', None) if take is not None else None
         if ctx.needs_input_grad[0]:
-            if ctx.x_shape[1] == 3:
-                raise Y4Error('gradient wrt the network input (stem, Cin=3) is not implemented')
+            if ctx.x_shape[1] == 3 and k == 3 and s == 1 and weight.shape[0] <= 32 and skip_grad is None:
+                dx = conv_stem_dgrad_raw(dy, weight, x)       # gradient wrt the network input (never needed in training)
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
-            if x_planes:
+            elif x_planes:
                 dx = conv_dgrad_planes_raw(Planes(dy, dy.shape, dy_amax), weight, ctx.x_shape, k, residual=skip_grad)
             else:
                 dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad)
@@ -784,8 +850,9 @@ class ConvBNActFn(torch.autograd.Function):
                     return conv_wgrad_planes_raw(Planes(x, x.shape, ctx.x_amax), Planes(dy, dy.shape, dy_amax),
                                                  tuple(weight.shape), k, out=out)
                 return conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=out, x_amax=x_amax, dy_amax=dy_amax)
-            if _ASYNC['on'] and param is not None and param.requires_grad and not x_planes:
-                _wgrad_to_param(x, dy, param, k, s, x_amax, dy_amax)   # lands in param.grad on the side stream
+            if _ASYNC['on'] and param is not None and param.requires_grad:
+                # lands in param.grad on the side stream
+                _wgrad_to_param(x, dy, param, k, s, ctx.x_amax if x_planes else x_amax, dy_amax, fn=wgrad if x_planes else None)
             elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
                 # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place
                 # (no temporary, no accumulate pass); the bucket is told directly, autograd gets None

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from ..optim.lr_schedulers.build import adjust_learning_rate
+from ... import trace
 from ..util.utils import detections_to_coco, postprocess
 
 
@@ -57,12 +58,16 @@ def train_step(cfg, model, criterion, optimizer, input, target, device=None, ste
         model.accumulating = not steps_now              # BucketedDDP: exchange once per window, on its last backward
     if device is not None:
         input = input.to(device)
-    output = model(input)                                                                        # :60
-    loss = criterion(output, target) / accumulation_steps                                       # :61
-    loss.backward()                                                                              # :64-65 (O0: scale 1)
+    with trace.range('y4.forward'):
+        output = model(input)                                                                    # :60
+    with trace.range('y4.loss'):
+        loss = criterion(output, target) / accumulation_steps                                   # :61
+    with trace.range('y4.backward'):
+        loss.backward()                                                                          # :64-65 (O0: scale 1)
     if steps_now:
-        optimizer.step()                                                                         # :67-69
-        optimizer.zero_grad()
+        with trace.range('y4.optimizer'):
+            optimizer.step()                                                                     # :67-69
+            optimizer.zero_grad()
     return loss
 
 
@@ -118,8 +123,10 @@ def validate(val_loader, model, conf_threshold, nms_threshold, device=None, eval
     for img, target in val_loader:
         assert isinstance(target, dict)
         infos = _img_infos(target['img_info'], img.shape[0])
-        outputs = model(img.to(device) if device is not None else img)                            # :133
-        outputs = postprocess(outputs, num_classes, conf_threshold, nms_threshold)                # :137
+        with trace.range('y4.eval_forward'):
+            outputs = model(img.to(device) if device is not None else img)                        # :133
+        with trace.range('y4.postprocess'):
+            outputs = postprocess(outputs, num_classes, conf_threshold, nms_threshold)            # :137
         for det, info in zip(outputs, infos):
             id_ = int(info[-2])
             ids.append(id_)
