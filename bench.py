@@ -49,6 +49,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=1)
     ap.add_argument('--no-kernel-events', action='store_true')
+    ap.add_argument('--all-kernel-events', action='store_true',
+                    help='HIP-event brackets around EVERY conv launch (per_symbol / all_conv_kernels cover all of them); default: '
+                         'only around the launches of the dominant kernel, conv_planes_mfma -- an event pair costs ~10 us of '
+                         'stream time, 3 ms per step over all ~330 conv launches (implied by --conv-table)')
     ap.add_argument('--ddp-timeline', action='store_true',
                     help='record when each gradient bucket becomes ready inside the backward pass (adds ddp_timeline to the line)')
     ap.add_argument('--conv-mode', default='f16x2', choices=['f16x2', 'bf16x3', 'f32', 'bf16'],
@@ -69,7 +73,7 @@ class ConvTimer:
         self.on = False
         self.sym = None
 
-    def wrap(self, ops):
+    def wrap(self, ops, only_dominant=False):
         timer = self
 
         def bracket(fn, kind, flops_of):
@@ -125,6 +129,8 @@ class ConvTimer:
 
         ops.conv_fwd_planes_bnstats_raw = bracket(ops.conv_fwd_planes_bnstats_raw, 'conv_fwd', f_fwd_p)
         ops.conv_dgrad_planes_raw = bracket(ops.conv_dgrad_planes_raw, 'conv_dgrad', f_dgrad_p)
+        if only_dominant:
+            return
         ops.conv_wgrad_planes_raw = bracket(ops.conv_wgrad_planes_raw, 'conv_wgrad', f_wgrad_p)
         ops.conv_fwd_raw = bracket(ops.conv_fwd_raw, 'conv_fwd', f_fwd)
         ops.conv_fwd_bnstats_raw = bracket(ops.conv_fwd_bnstats_raw, 'conv_fwd', f_fwd)   # conv + BN-stat epilogue + fold
@@ -150,17 +156,22 @@ class ConvTimer:
             a[2] += 1
         return {k: {'tflops': v[0] / v[1] / 1e12, 'seconds': v[1], 'launches': v[2], 'flop': v[0]} for k, v in agg.items()}
 
-    def table(self, steps):
+    def table(self, steps, batch=64):
+        """Per layer shape and kernel: launches and ms per step, TFLOP/s, and TB/s over the unavoidable bytes (input + output
+        tensor once each, 4 B per element) -- the second tells which rows are HBM-bound rather than MFMA-bound."""
         agg = {}
-        for kind, fl, e0, e1, key, _sym in self.rec:
-            a = agg.setdefault((kind,) + key, [0.0, 0.0, 0])
+        for kind, fl, e0, e1, key, sym in self.rec:
+            a = agg.setdefault((kind,) + key + ((sym or '?').split('(')[0],), [0.0, 0.0, 0])
             a[0] += fl
             a[1] += e0.elapsed_time(e1) * 1e-3
             a[2] += 1
         rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
-        lines = ['kind        Cin  Cout k s  Hin   n/step  ms/step  TFLOP/s']
-        for (kind, cin, cout, k, s, h), v in rows:
-            lines.append(f'{kind:10s} {cin:5d} {cout:5d} {k} {s} {h:4d} {v[2] / steps:7.1f} {v[1] / steps * 1e3:8.2f} {v[0] / v[1] / 1e12:8.1f}')
+        lines = ['kind        Cin  Cout k s  Hin   n/step  ms/step  TFLOP/s   TB/s  kernel']
+        for (kind, cin, cout, k, s, h, sym), v in rows:
+            ho = (h + 2 * ((k - 1) // 2) - k) // s + 1
+            nbytes = 4.0 * batch * (h * h * cin + ho * ho * cout) * v[2]
+            lines.append(f'{kind:10s} {cin:5d} {cout:5d} {k} {s} {h:4d} {v[2] / steps:7.1f} {v[1] / steps * 1e3:8.2f} {v[0] / v[1] / 1e12:8.1f} '
+                         f'{nbytes / v[1] / 1e12:6.2f}  {sym}')
         return '\n'.join(lines)
 
 
@@ -429,8 +440,9 @@ def main():
     yolov4_amd.set_conv_mode(args.conv_mode)
     _ARGS['conv_mode'] = args.conv_mode
     timer = ConvTimer()
+    all_events = args.all_kernel_events or bool(args.conv_table) or args.conv_mode != 'f16x2' or not ops.PLANES['on']
     if not args.no_kernel_events:
-        timer.wrap(ops)
+        timer.wrap(ops, only_dominant=not all_events)
 
     cfg = recipe.MODEL_CFG
     torch.manual_seed(0)
@@ -534,7 +546,8 @@ def main():
                                'traffic': traffic,
                                'kernel': dsym,
                                'measured': 'achieved / frac / avg_launch_ms / per_symbol: LIVE in this run (HIP events on the launch '
-                                           'stream around every conv launch of the timed steps)',
+                                           'stream around ' + ('every conv launch' if all_events else 'every launch of the dominant kernel '
+                                           '(--all-kernel-events: all conv launches)') + ' of the timed steps)',
                                'recorded': {'note': 'PMC counters cannot be read from inside the process: traffic and mfma_util_pmc are '
                                                     'RECORDED values of separate rocprofv3 --pmc passes of this same command, not '
                                                     'measurements of this run; null when no recording of this kernel symbol exists',
@@ -556,7 +569,7 @@ def main():
                                               for k, v in sorted(syms.items(), key=lambda kv: -kv[1]['seconds'])}}
         if args.conv_table and timer.rec:
             with open(args.conv_table, 'w') as f:
-                f.write(timer.table(args.steps) + '\n')
+                f.write(timer.table(args.steps, B) + '\n')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(S, args.cpu_batch)
             # the HIP path on configs[0] beside it (same shape; parity at this shape: tests/test_gpu_round2.py config0 test)

@@ -1,29 +1,94 @@
-"""Micro-benchmark of the BatchNorm+activation sweeps (HBM-bound): achieved TB/s per kernel family.
-usage: python scripts/bn_micro.py [reps]"""
-import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, R)
+# -*- coding: utf-8 -*-
+"""BatchNorm sweeps of the bs = 64 @608 training step, IN SITU: every `bn_act_fwd_raw` / `bn_act_bwd_raw` call of the timed
+steps is bracketed by HIP events and aggregated per (M, C, act, residual, plane mode) -- launches, ms per step, achieved
+TB/s over the algorithmic bytes (fwd: read y [+ residual], write z; bwd: 2 reads in the reduce pass, 2 reads + 1 write in
+the apply pass).  The caches are in whatever state the step leaves them, which is the state that matters.
+
+    python scripts/bn_micro.py [batch] [steps]
+"""
+import collections
+import json
+import sys
+
 import torch
-from yolov4_amd import ops
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-dev = torch.device('cuda:0')
-B = 64
-for (C, H) in [(64, 304), (128, 152), (256, 76), (512, 38), (1024, 19), (32, 608)]:
-    y = torch.randn((B, C, H, H), device=dev).contiguous(memory_format=torch.channels_last)
-    dz = torch.randn_like(y)
-    g = torch.rand(C, device=dev) + 0.5; b = torch.randn(C, device=dev) * 0.1
-    mean, invstd = ops.bn_stats_raw(y, None, None, None, 0.1, 1e-5)
-    nbytes = y.numel() * 4
-    def timeit(fn):
-        fn(); torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps): fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-    t_f = timeit(lambda: ops.bn_act_fwd_raw(y, mean, invstd, g, b, 'mish'))
-    t_b = timeit(lambda: ops.bn_act_bwd_raw(dz, y, mean, invstd, g, b, 'mish'))
-    t_c = timeit(lambda: y.clone())
-    t_s = timeit(lambda: ops.bn_stats_raw(y, None, None, None, 0.1, 1e-5))
-    print(f'C={C:5d} H={H:3d} {nbytes/1e6:7.0f} MB | fwd {t_f:6.3f} ms {2*nbytes/t_f/1e9:5.2f} TB/s | bwd(reduce+apply) {t_b:6.3f} ms {5*nbytes/t_b/1e9:5.2f} TB/s | stats {t_s:6.3f} ms {nbytes/t_s/1e9:5.2f} TB/s | torch clone {2*nbytes/t_c/1e9:5.2f} TB/s', flush=True)
-    del y, dz
+
+import os  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    import recipe
+    from yolov4_amd import ops
+    from yolov4_amd.yolo.model.yolov4 import YOLOv4
+    from yolov4_amd.yolo.model.yololoss import YOLOLoss
+    dev = torch.device('cuda:0')
+    rec = []
+    state = {'on': False}
+
+    def bracket(fn, kind):
+        def inner(*a, **kw):
+            if not state['on']:
+                return fn(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            if kind == 'fwd':
+                y, act, res = a[0], a[5], (a[6] if len(a) > 6 else kw.get('residual'))
+                sweeps = 2 + (1 if res is not None else 0) + (1 if kw.get('planes') == 'both' else 0)
+                key = ('fwd', tuple(y.shape), act, res is not None, str(kw.get('planes', False)))
+            else:
+                y, act = a[1], a[6]
+                sweeps = 5
+                key = ('bwd', tuple(y.shape), act, False, 'planes' if kw.get('planes') is not None else 'f32')
+            rec.append((key, y.numel() * 4 * sweeps, e0, e1))
+            return r
+        return inner
+    ops.bn_act_fwd_raw = bracket(ops.bn_act_fwd_raw, 'fwd')
+    ops.bn_act_bwd_raw = bracket(ops.bn_act_bwd_raw, 'bwd')
+
+    cfg = recipe.MODEL_CFG
+    m = YOLOv4(cfg, device=dev)
+    sd = m.state_dict()
+    recipe.fill_state_dict_(sd, 1234)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    crit = YOLOLoss(cfg, ignore_thresh=0.7, device=dev)
+    x = recipe.randn((B, 3, 608, 608), 5).to(dev)
+    labels = recipe.synth_labels(B, 608, 6).to(dev)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        crit(m(x), {'padded_labels': labels}).backward()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    state['on'] = True
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    state['on'] = False
+    agg = collections.OrderedDict()
+    for key, nbytes, e0, e1 in rec:
+        a = agg.setdefault(key, [0, 0.0, 0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += nbytes
+    tot = {'fwd': 0.0, 'bwd': 0.0}
+    rows = []
+    for key, (n, ms, nb) in agg.items():
+        tot[key[0]] += ms / steps
+        rows.append({'kind': key[0], 'shape': list(key[1]), 'act': key[2], 'res': key[3], 'mode': key[4], 'per_step': n // steps,
+                     'ms_per_step': round(ms / steps, 3), 'us_per_call': round(ms / n * 1e3, 1), 'TBps': round(nb / ms / 1e9, 2)})
+    rows.sort(key=lambda r: -r['ms_per_step'])
+    for r in rows:
+        print(json.dumps(r))
+    print(json.dumps({'total_ms_per_step': {k: round(v, 2) for k, v in tot.items()}, 'env': {k: v for k, v in __import__('os').environ.items() if k.startswith('Y4_')}}))
+
+
+if __name__ == '__main__':
+    main()

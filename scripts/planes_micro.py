@@ -7,8 +7,10 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
-sys.path.insert(0, 'tests')
+import os  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from yolov4_amd import ops  # noqa: E402
 
 SHAPES = [  # ci, co, k, s, H

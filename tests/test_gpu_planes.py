@@ -35,6 +35,8 @@ PLANE_CASES = [
     (2, 128, 256, 3, 1, 19, 19),      # two N tiles, M = 722 (three tiles, ragged)
     (1, 32, 36, 3, 1, 40, 40),        # Cout % 4 == 0 only
     (2, 2048, 512, 1, 1, 5, 5),
+    (5, 256, 128, 1, 1, 7, 7),        # K <= 256: the 128-row two-blocks-per-CU shape, tiles spanning images
+    (3, 256, 512, 1, 1, 19, 19),      # same shape of kernel, four N tiles, ragged M = 1083
 ]
 
 
@@ -55,7 +57,7 @@ def test_planes_forward_matches_torch_and_the_register_staged_kernel(dev, case):
     assert float((y - y0).abs().max()) <= 2e-6 * float(ref.abs().max())
     # column sums of the epilogue = sums of the stored result
     M = y.shape[0] * y.shape[2] * y.shape[3]
-    assert n == (M + 255) // 256
+    assert n == ((M + 127) // 128 if k * k * ci <= 256 else (M + 255) // 256)      # 128-row tiles for short K (conv_planes.hip)
     ps = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()), dtype=torch.float32)[:n * 2 * co].view(n, 2, co).double().sum(0)
     yy = y.double().cpu().permute(0, 2, 3, 1).reshape(-1, co)
     assert torch.allclose(ps[0], yy.sum(0), rtol=1e-5, atol=1e-4 * float(yy.abs().max()))

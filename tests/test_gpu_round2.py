@@ -7,6 +7,7 @@ the drop-in BucketedDDP loop, and the packaged train / validate harness."""
 import copy
 import gc
 import math
+import os
 
 import numpy as np
 import pytest
@@ -546,8 +547,12 @@ def test_inference_filter_cache_is_exact_and_expires_with_the_weights(dev):
 
     def uncached():
         m.eval()
-        with torch.enable_grad():                      # grad mode on: the per-call path (amax + split inside the call)
-            return m(x).detach().clone()
+        os.environ['Y4_NO_INFER_CACHE'] = '1'          # the per-call path (amax + split inside the call), same fused epilogue
+        try:
+            with torch.no_grad():
+                return m(x).clone()
+        finally:
+            del os.environ['Y4_NO_INFER_CACHE']
 
     def cached():
         m.eval()

@@ -53,14 +53,20 @@ struct PlaneConvGeom {
 
 constexpr int PROW = 128;                                  // bytes per LDS row: one 32-deep K-tile, [64 B hi | 64 B lo]
 
+// Two shapes of the same kernel:
+//   <256, 128, 4, 2>: 8 waves, three 48-KB stages, ONE block per CU -- the MFMA-bound layers (3x3, long K).
+//   <128, 128, 2, 2>: 4 waves, two 32-KB stages, TWO blocks per CU -- short-K layers (1x1 with K <= a few hundred), which
+//                     are HBM-bound: with one block per CU its load, MFMA and store phases run back to back and the
+//                     memory pipes idle for most of them; two co-resident blocks overlap one's epilogue with the other's loads.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g) {
-    constexpr int NWAVE = 8;
-    static_assert(WM * WN == NWAVE, "8 waves");
+__global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_planes_mfma(const PlaneConvGeom g) {
+    constexpr int NWAVE = WM * WN, NTHR = NWAVE * 64;
+    static_assert(NWAVE == 8 || NWAVE == 4, "8 or 4 waves");
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_BYTES = BM * PROW, B_BYTES = BN * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    constexpr int A_BYTES = BM * PROW, B_BYTES = BN * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = NWAVE == 8 ? 3 : 2;
     constexpr int PA = BM / 8 / NWAVE, PB = BN / 8 / NWAVE, NDMA = PA + PB;      // 1-KiB DMA pieces per wave and K-tile
-    static_assert(PA >= 1 && PB >= 1 && NDMA == 6, "the counted vmcnt below assumes 6 pieces per wave and K-tile");
+    static_assert(PA >= 1 && PB >= 1 && ((NSTAGE == 3 && NDMA == 6) || (NSTAGE == 2 && NDMA == 8)),
+                  "the counted vmcnt below assumes 6 (three stages) or 8 (two stages) pieces per wave and K-tile");
     typedef float accv __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -144,7 +150,7 @@ __global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g
         }
     };
     using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
-    using I6 = std::integral_constant<int, NDMA>;
+    using I6 = std::integral_constant<int, NDMA>;          // (= all pieces of a K-tile)
 
     accv acc0[TM][TN], acc1[TM][TN];
 #pragma unroll
@@ -183,10 +189,18 @@ __global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g
             if (i == TM - 1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of stage S has returned
                 if (kt + 1 < KT) {
-                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    if (kt + 3 < KT) { issue(S, I0{}, I2{}); pend = true; }
+                    if constexpr (NSTAGE == 3) {
+                        if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        if (kt + 3 < KT) { issue(S, I0{}, I2{}); pend = true; }
+                    } else {
+                        // two stages: only tile t + 1 is in flight (issued one whole step ago); the other block on this CU
+                        // covers the rest of the latency.  All of tile t + 2 goes out at once into the stage just freed.
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        if (kt + 2 < KT) issue(S, I0{}, I6{});
+                    }
                 }
             }
 #pragma unroll
@@ -195,18 +209,25 @@ __global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g
                 acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
                 acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
             }
-            if (i == 0 && pend) issue((S + 2) % NSTAGE, I2{}, I4{});
-            if (i == 1 && pend) { issue((S + 2) % NSTAGE, I4{}, I6{}); pend = false; }
+            if constexpr (NSTAGE == 3) {
+                if (i == 0 && pend) issue((S + 2) % NSTAGE, I2{}, I4{});
+                if (i == 1 && pend) { issue((S + 2) % NSTAGE, I4{}, I6{}); pend = false; }
+            }
         }
     };
     static_assert(TM >= 3, "the DMA pieces are spread over the first three row tiles");
 
-    for (int t = 0; t < 3 && t < KT; ++t) issue(t, I0{}, I6{});
-    if (KT >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (KT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = 0; t < NSTAGE && t < KT; ++t) issue(t, I0{}, I6{});
+    if constexpr (NSTAGE == 3) {
+        if (KT >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (KT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (KT >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
-    {
+    if constexpr (NSTAGE == 3) {
         int kt = 0;
         for (; kt + 3 <= KT; kt += 3) {
             step(std::integral_constant<int, 0>{}, kt);
@@ -215,6 +236,13 @@ __global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g
         }
         if (kt < KT) step(std::integral_constant<int, 0>{}, kt);
         if (kt + 1 < KT) step(std::integral_constant<int, 1>{}, kt + 1);
+    } else {
+        int kt = 0;
+        for (; kt + 2 <= KT; kt += 2) {
+            step(std::integral_constant<int, 0>{}, kt);
+            step(std::integral_constant<int, 1>{}, kt + 1);
+        }
+        if (kt < KT) step(std::integral_constant<int, 0>{}, kt);
     }
 
     // ---- epilogue: c = (acc0 + 2^-11 acc1) / (s_A s_B); 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + e.
@@ -224,7 +252,8 @@ __global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g
     const float un1 = un * (1.0f / 2048.0f);
     __syncthreads();                                       // every wave has left the last stage
     constexpr int EP = WTN + 4;
-    static_assert(NWAVE * WTM * EP * 4 + WM * BN * 2 * 4 <= NSTAGE * STAGE, "epilogue patches + column sums must fit the stages");
+    constexpr int EPI_BYTES = NWAVE * WTM * EP * 4 + WM * BN * 2 * 4;       // epilogue patches + column sums
+    static_assert(EPI_BYTES <= (NSTAGE * STAGE > 72 * 1024 ? NSTAGE * STAGE : 72 * 1024), "epilogue must fit the dynamic LDS (launcher: max of the two)");
     float* patch = reinterpret_cast<float*>(smem) + wave * (WTM * EP);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -277,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void conv_planes_mfma(const PlaneConvGeom g
             }
         }
         __syncthreads();
-        for (int c = tid; c < BN; c += 512) {
+        for (int c = tid; c < BN; c += NTHR) {
             float cs = 0.f, css = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { cs += red[(w * BN + c) * 2]; css += red[(w * BN + c) * 2 + 1]; }
@@ -432,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
         }
     };
     using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
-    using I6 = std::integral_constant<int, NDMA>;
+    using I6 = std::integral_constant<int, NDMA>;          // (= all pieces of a K-tile)
 
     accv acc0[TM][TN], acc1[TM][TN];
 #pragma unroll
@@ -558,7 +587,11 @@ int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     PlaneConvGeom g = g0;
     g.mtiles = (g.M + BM - 1) / BM;
     g.ntiles = (g.N + BN - 1) / BN;
-    constexpr size_t smem = 3ull * (BM + BN) * PROW;
+    constexpr int NW = WM * WN;
+    constexpr size_t stages = (NW == 8 ? 3ull : 2ull) * (BM + BN) * PROW;
+    constexpr size_t epi = (size_t)NW * (BM / WM) * (BN / WN + 4) * 4 + (size_t)WM * BN * 2 * 4;
+    constexpr size_t smem = stages > epi ? stages : epi;
+    static_assert(NW == 8 || 2 * smem <= 160 * 1024, "two blocks per CU");
     auto kern = conv_planes_mfma<BM, BN, WM, WN>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -567,7 +600,7 @@ int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
         attr_done = true;
     }
     y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d>", BM, BN, WM, WN);
-    hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(512), smem, st, g);
+    hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -603,8 +636,12 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
     g.src_total_bytes = (unsigned long long)B * img;
     g.wt_bytes = (unsigned)wb;
     g.src_amax = src_amax; g.wt_amax = wt_amax;
-    if (nparts) *nparts = (g.M + 255) / 256;
-    return launch_conv_planes<256, 128, 4, 2>(g, st);
+    // short K (1x1 layers up to 256 input channels): the two-blocks-per-CU shape (3-8 % faster there, measured; from K = 512
+    // on the 256-row shape wins again).  Y4_PLANES_SMALL = 0 never, 2 always (experiments)
+    static const int small_mode = getenv("Y4_PLANES_SMALL") ? atoi(getenv("Y4_PLANES_SMALL")) : 1;
+    const bool small = small_mode == 2 || (small_mode == 1 && g.K <= 256);
+    if (nparts) *nparts = small ? (g.M + 127) / 128 : (g.M + 255) / 256;
+    return small ? launch_conv_planes<128, 128, 2, 2>(g, st) : launch_conv_planes<256, 128, 4, 2>(g, st);
 }
 
 // split-K plan of the plane wgrad: tiles x splits blocks on 256 CUs (one block per CU), minimising rounds x K-steps per block
@@ -698,7 +735,7 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
         (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return Y4_ERR_SHAPE;
     const int pad = (k - 1) / 2;
     const long long M = (long long)B * ((H + 2 * pad - k) / stride + 1) * ((W + 2 * pad - k) / stride + 1);
-    if (partials && partial_bytes < (size_t)((M + 255) / 256) * 2 * Cout * sizeof(float)) return Y4_ERR_WORKSPACE;
+    if (partials && partial_bytes < (size_t)((M + 127) / 128) * 2 * Cout * sizeof(float)) return Y4_ERR_WORKSPACE;   // 128-row tiles at most
     hipStream_t st = y4_stream(stream);
     unsigned* hdr = static_cast<unsigned*>(workspace);
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + 64 + 4096);

@@ -8,6 +8,7 @@
 namespace {
 
 constexpr int PW_THREADS = 256;
+constexpr int PW_UNROLL = 4;               // rows in flight per thread in the streaming sweeps
 
 struct RowMap {            // thread -> (channel vector, row group)
     int tpr;               // threads per row (channel vectors handled concurrently)
@@ -126,8 +127,22 @@ __device__ __forceinline__ void fold_rows32(const double* __restrict__ bacc, int
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;           // 256 threads = 8 groups x 32 channels
     const int c = c0 + cl;
     double a = 0, b2 = 0;
-    if (c < C)
-        for (int r = g; r < nb; r += 8) { a += bacc[(long long)r * 2 * C + c]; b2 += bacc[(long long)r * 2 * C + C + c]; }
+    if (c < C) {
+        // 8 rows (16 loads) in flight per trip: one row per trip made this a chain of nb / 8 dependent memory round trips
+        // (12 us for nb = 256, measured); the adds stay in row order, so the sums are unchanged
+        int r = g;
+        for (; r + 56 < nb; r += 64) {
+            double va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = bacc[(long long)(r + 8 * u) * 2 * C + c];
+                vb[u] = bacc[(long long)(r + 8 * u) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += va[u]; b2 += vb[u]; }
+        }
+        for (; r < nb; r += 8) { a += bacc[(long long)r * 2 * C + c]; b2 += bacc[(long long)r * 2 * C + C + c]; }
+    }
     red[0][g][cl] = a; red[1][g][cl] = b2;
     __syncthreads();
     s = 0; ss = 0;
@@ -210,6 +225,41 @@ __global__ __launch_bounds__(256) void bn_planes_bound_kernel(const float* __res
     }
 }
 
+
+// Plane output of a sweep whose threads hold 4 consecutive channels each: the two fp16 pieces of the f16x2 split leave as
+// WHOLE 16-B chunks -- lanes 2k / 2k + 1 (channels 8j..8j+3 / 8j+4..8j+7 of one pixel) swap halves through DPP, the even
+// lane stores the 16 B of hi, the odd lane the 16 B of lo -- so 8 lanes write one complete 128-B line [64 B hi | 64 B lo]
+// with one store instruction each, instead of two 8-B stores per lane into half lines.
+__device__ __forceinline__ unsigned pair_swap(unsigned v) {              // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void store_planes4(unsigned char* row_base, int c0, const f32x4 o, float ps, bool paired) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    h2 h01, h23, l01, l23;
+    const float t0 = o[0] * ps, t1 = o[1] * ps, t2 = o[2] * ps, t3 = o[3] * ps;
+    h01[0] = (_Float16)t0; h01[1] = (_Float16)t1; h23[0] = (_Float16)t2; h23[1] = (_Float16)t3;
+    l01[0] = (_Float16)((t0 - (float)h01[0]) * 2048.f); l01[1] = (_Float16)((t1 - (float)h01[1]) * 2048.f);
+    l23[0] = (_Float16)((t2 - (float)h23[0]) * 2048.f); l23[1] = (_Float16)((t3 - (float)h23[1]) * 2048.f);
+    const unsigned hv0 = __builtin_bit_cast(unsigned, h01), hv1 = __builtin_bit_cast(unsigned, h23);
+    const unsigned lv0 = __builtin_bit_cast(unsigned, l01), lv1 = __builtin_bit_cast(unsigned, l23);
+    unsigned char* tile = row_base + (c0 >> 5) * 128;
+    if (paired) {                                                        // uniform: C % 8 == 0 and both lanes of a pair active
+        const bool odd = (c0 & 4) != 0;
+        const unsigned r0 = pair_swap(odd ? hv0 : lv0), r1 = pair_swap(odd ? hv1 : lv1);
+        u4 v;
+        if (odd) { v[0] = r0; v[1] = r1; v[2] = lv0; v[3] = lv1; }      // lo of channels 8j .. 8j+7
+        else { v[0] = hv0; v[1] = hv1; v[2] = r0; v[3] = r1; }           // hi of channels 8j .. 8j+7
+        *reinterpret_cast<u4*>(tile + (odd ? 64 : 0) + ((c0 & 24) >> 3) * 16) = v;
+    } else {
+        u2 hv, lv;
+        hv[0] = hv0; hv[1] = hv1; lv[0] = lv0; lv[1] = lv1;
+        *reinterpret_cast<u2*>(tile + (c0 & 31) * 2) = hv;
+        *reinterpret_cast<u2*>(tile + 64 + (c0 & 31) * 2) = lv;
+    }
+}
+
 // ---------------------------------------------------------------- BN apply + act (+ skip)
 __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -225,6 +275,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const int cv = tid % tpr, rg = tid / tpr;
     unsigned amax = 0u;
     float ps = 1.f;
+    const bool paired = (C & 7) == 0 && tpr >= 2;         // lanes 2k, 2k + 1: same pixel, adjacent channel quads, both in range
     if (planes) {
         const unsigned e8 = (*out_amax >> 23) & 0xffu;
         int se = 268 - (int)e8;                            // as f16x2_scale_exp (conv_f16x2.hip)
@@ -239,29 +290,35 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
             a[e] = invstd[c0 + e] * gamma[c0 + e];
             b[e] = beta[c0 + e] - mean[c0 + e] * a[e];
         }
-        for (long long m = (long long)blockIdx.x * rpb + rg; m < M; m += (long long)gridDim.x * rpb) {
-            f32x4 v = ld4(y + m * ldy + c0);
-            f32x4 o;
+        // PW_UNROLL row groups per trip, every load issued before the first use, and the block's rows of a trip CONTIGUOUS:
+        // all blocks together advance one front through the tensor (rows of a trip spread gridDim apart: 10 % slower, measured)
+        const long long stride = (long long)gridDim.x * rpb;
+        for (long long t0 = 0; t0 * stride * PW_UNROLL < M; ++t0) {
+            f32x4 v[PW_UNROLL], r[PW_UNROLL];
+            long long mm[PW_UNROLL];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = y4_act(v[e] * a[e] + b[e], act);
-            if (res) o += ld4(res + m * ldr + c0);
-            if (planes) {
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                h4 hi, lo;
+            for (int u = 0; u < PW_UNROLL; ++u) {
+                const long long m = ((t0 * gridDim.x + blockIdx.x) * PW_UNROLL + u) * rpb + rg;
+                mm[u] = m < M ? m : -1;
+                const long long ml = mm[u] < 0 ? 0 : mm[u];
+                v[u] = ld4(y + ml * ldy + c0);
+                if (res) r[u] = ld4(res + ml * ldr + c0);
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = o[e] * ps;
-                    hi[e] = (_Float16)t;
-                    lo[e] = (_Float16)((t - (float)hi[e]) * 2048.f);
+            for (int u = 0; u < PW_UNROLL; ++u) {
+                if (mm[u] < 0) continue;
+                const long long m = mm[u];
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = y4_act(v[u][e] * a[e] + b[e], act);
+                if (res) o += r[u];
+                if (planes) {
+                    store_planes4(reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : z + m * ldz), c0, o, ps, paired);
+                    if (twin) st4(z + m * ldz + c0, o);
+                } else {
+                    if (z) st4(z + m * ldz + c0, o);
+                    amax_track(amax, o);
                 }
-                unsigned char* row = reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : z + m * ldz) +
-                                     (c0 >> 5) * 128 + (c0 & 31) * 2;
-                *reinterpret_cast<h4*>(row) = hi;
-                *reinterpret_cast<h4*>(row + 64) = lo;
-                if (twin) st4(z + m * ldz + c0, o);
-            } else {
-                if (z) st4(z + m * ldz + c0, o);
-                amax_track(amax, o);
             }
         }
     }
@@ -396,6 +453,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const int cv = tid % tpr, rg = tid / tpr;
     const double invM = frozen ? 0.0 : 1.0 / (double)M;    // frozen statistics: no batch-statistic terms in dy
     unsigned amax = 0u;
+    const bool paired = (C & 7) == 0 && tpr >= 2;
     // plane output (conv mode 3): dy leaves as the two fp16 pieces the conv kernels would otherwise split it into,
     // per pixel and 32-channel K tile [64 B hi | 64 B scaled lo] in the 4C bytes of the fp32 row.  The scale needs max|dy| BEFORE the
     // sweep: |dy| <= max|gamma invstd| (max|g| + max|k1| + max|xhat| max|k2|), all five maxima left by the reduce /
@@ -420,33 +478,35 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
             k1[e] = (float)(acc[c0 + e] * invM);
             k2[e] = (float)(acc[C + c0 + e] * invM);
         }
-        for (long long m = (long long)blockIdx.x * rpb + rg; m < M; m += (long long)gridDim.x * rpb) {
-            const f32x4 v = ld4(y + m * ldy + c0);
-            const f32x4 d = ld4(dz + m * lddz + c0);
-            f32x4 o;
+        const long long stride = (long long)gridDim.x * rpb;
+        for (long long t0 = 0; t0 * stride * PW_UNROLL < M; ++t0) {
+            f32x4 v[PW_UNROLL], d[PW_UNROLL];
+            long long mm[PW_UNROLL];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (v[e] - mu[e]) * is[e];
-                const float g = d[e] * y4_act_grad(ga[e] * xh + be[e], act);
-                o[e] = ga[e] * is[e] * (g - k1[e] - xh * k2[e]);
+            for (int u = 0; u < PW_UNROLL; ++u) {
+                const long long m = ((t0 * gridDim.x + blockIdx.x) * PW_UNROLL + u) * rpb + rg;
+                mm[u] = m < M ? m : -1;
+                const long long ml = mm[u] < 0 ? 0 : mm[u];
+                v[u] = ld4(y + ml * ldy + c0);
+                d[u] = ld4(dz + ml * lddz + c0);
             }
-            if (bounds) {
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                h2 h01, h23, l01, l23;
-                const float t0 = o[0] * ps, t1 = o[1] * ps, t2 = o[2] * ps, t3 = o[3] * ps;
-                h01[0] = (_Float16)t0; h01[1] = (_Float16)t1; h23[0] = (_Float16)t2; h23[1] = (_Float16)t3;
-                l01[0] = (_Float16)((t0 - (float)h01[0]) * 2048.f); l01[1] = (_Float16)((t1 - (float)h01[1]) * 2048.f);
-                l23[0] = (_Float16)((t2 - (float)h23[0]) * 2048.f); l23[1] = (_Float16)((t3 - (float)h23[1]) * 2048.f);
-                unsigned char* row = reinterpret_cast<unsigned char*>(dy + m * lddy) + (c0 >> 5) * 128 + (c0 & 31) * 2;
-                typedef unsigned u2 __attribute__((ext_vector_type(2)));
-                u2 hv, lv;
-                hv[0] = __builtin_bit_cast(unsigned, h01); hv[1] = __builtin_bit_cast(unsigned, h23);
-                lv[0] = __builtin_bit_cast(unsigned, l01); lv[1] = __builtin_bit_cast(unsigned, l23);
-                *reinterpret_cast<u2*>(row) = hv;          // per 32-channel K tile: [64 B hi | 64 B lo] (conv_planes.hip)
-                *reinterpret_cast<u2*>(row + 64) = lv;
-            } else {
-                st4(dy + m * lddy + c0, o);
-                amax_track(amax, o);
+#pragma unroll
+            for (int u = 0; u < PW_UNROLL; ++u) {
+                if (mm[u] < 0) continue;
+                const long long m = mm[u];
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (v[u][e] - mu[e]) * is[e];
+                    const float g = d[u][e] * y4_act_grad(ga[e] * xh + be[e], act);
+                    o[e] = ga[e] * is[e] * (g - k1[e] - xh * k2[e]);
+                }
+                if (bounds) {
+                    store_planes4(reinterpret_cast<unsigned char*>(dy + m * lddy), c0, o, ps, paired);
+                } else {
+                    st4(dy + m * lddy + c0, o);
+                    amax_track(amax, o);
+                }
             }
         }
     }
@@ -825,7 +885,7 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (!vec_ok(y, ldy, C) || (z && !vec_ok(z, ldz, C)) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
         return Y4_ERR_SHAPE;
     const RowMap rm = row_map(C);
-    long long blocks = (M + rm.rpb - 1) / rm.rpb;
+    long long blocks = (M + rm.rpb * PW_UNROLL - 1) / (rm.rpb * PW_UNROLL);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
                        (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
@@ -862,7 +922,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta, gamma,
                        invstd, 1.0 / (double)M, f16_planes);
     Y4_CHECK_LAUNCH();
-    long long blocks = (M + rm.rpb - 1) / rm.rpb;
+    long long blocks = (M + rm.rpb * PW_UNROLL - 1) / (rm.rpb * PW_UNROLL);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
                        (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,

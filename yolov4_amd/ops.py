@@ -335,7 +335,7 @@ def planes_split_raw(x, amax=None):
 
 
 def conv_fwd_planes_raw(xp, w, k, s, stats=True):
-    """Training-mode conv over a Planes input: raw output y (+ per-256-row-tile column sums, n_tiles)."""
+    """Training-mode conv over a Planes input: raw output y (+ per-M-tile column sums, n_tiles)."""
     L = lib()
     B, Cin, H, W = xp.shape
     Cout = w.shape[0]
@@ -344,7 +344,7 @@ def conv_fwd_planes_raw(xp, w, k, s, stats=True):
     w = krsc(w)
     nbytes = L.y4_conv2d_fwd_workspace(Cin, Cout, k)
     ws = _ws(nbytes, xp.buf.device)
-    pbytes = ((B * Ho * Wo + 255) // 256) * 2 * Cout * 4 if stats else 0
+    pbytes = ((B * Ho * Wo + 127) // 128) * 2 * Cout * 4 if stats else 0       # 128-row tiles at most
     part = _ws(pbytes, xp.buf.device) if stats else None
     n = ctypes.c_longlong(0)
     check(L.y4_conv2d_fwd_planes_f32(_ptr(xp.buf), _ptr(w), _ptr(y), nhwc_pitch(y), B, H, W, Cin, Cout, k, s,
