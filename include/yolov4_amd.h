@@ -125,27 +125,33 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
                               int B, int H, int W, int Cin, int Cout, int k, int stride,
                               float* partials, size_t partial_bytes, long long* nparts_host,
                               const unsigned* x_amax /* mode 3, nullable */,
-                              void* workspace, size_t workspace_bytes /* as y4_conv2d_fwd_f32 */, void* stream);
+                              void* workspace, size_t workspace_bytes /* as y4_conv2d_fwd_f32 */,
+                              void* dgrad_filter /* nullable; mode 3: also receives the transposed filter planes, in the layout of
+                                 y4_conv2d_dgrad_f32's workspace -- that call then takes this buffer as its workspace with
+                                 w == NULL and launches no filter kernels (one split launch serves forward and backward) */,
+                              size_t dgrad_filter_bytes /* >= y4_conv2d_dgrad_workspace(Cin, Cout, k) */, void* stream);
 
 /* ---- conv mode 3 over PRE-SPLIT activations ("planes", csrc/conv_planes.hip): the input arrives as the two fp16 pieces
  * of the f16x2 split, per pixel and 32-channel K tile [64 B: 32 hi halfs | 64 B: 32 scaled-lo halfs] (4 bytes per element,
  * pitch 4 Cin bytes, Cin % 32 == 0), scaled by the power of two that *x_amax (an upper bound of max|x|) implies; that is
  * the form the BatchNorm sweeps can emit directly, and the form LDS-DMA can stage without touching the VALU.
  * y4_planes_split_f32 converts an fp32 NHWC tensor (tests, tensors produced by kernels that do not emit planes).
- * y4_conv2d_fwd_planes_f32 = y4_conv2d_fwd_bnstats_f32 on such an input (raw output + per-256-row-tile column sums;
+ * y4_conv2d_fwd_planes_f32 = y4_conv2d_fwd_bnstats_f32 on such an input (raw output + per-M-tile column sums, 256- or 128-row tiles;
  * partials may be NULL); workspace as y4_conv2d_fwd_f32.  Replaces the same nn.Conv2d, darknet/darknet.py:31-36,53-54. */
 int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, void* stream);
 int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,
                              int B, int H, int W, int Cin, int Cout, int k, int stride,
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             void* workspace, size_t workspace_bytes,
+                             void* dgrad_filter /* nullable, stride 1: as in y4_conv2d_fwd_bnstats_f32, for y4_conv2d_dgrad_planes_f32 */,
+                             size_t dgrad_filter_bytes, void* stream);
 
 /* dgrad / wgrad of a STRIDE-1 conv over planes (dy, and for wgrad also x, pre-split as above; Cin % 32 == 0, Cout % 32 == 0):
  * the same arithmetic as y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 in conv mode 3.  dgrad runs the forward DMA kernel on the
  * mirrored transposed filter (workspace: y4_conv2d_dgrad_workspace()); wgrad stages both operands pixel-major and takes its
  * fragments through the hardware transpose read (split-K slabs in y4_conv2d_wgrad_planes_workspace() bytes, fixed-order
  * reduce: deterministic).  Autograd of the same nn.Conv2d, darknet/darknet.py:31-36. */
-int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx, int lddx,
+int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w /* NULL: workspace prepared by the forward call */, float* dx, int lddx,
                                int B, int H, int W, int Cin, int Cout, int k,
                                void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                                const float* residual, int ldr, void* stream);
@@ -184,7 +190,7 @@ int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long lo
  * residual (nullable, pitch ldr >= Cin): added in the epilogue -- the gradient arriving over a ResBlock's skip
  * connection (darknet/darknet.py:76-80: x + f(x)), so the fan-in add costs no extra pass. */
 size_t y4_conv2d_dgrad_workspace(int Cin, int Cout, int k);
-int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w, float* dx, int lddx,
+int y4_conv2d_dgrad_f32(const float* dy, int lddy, const float* w /* mode 3: NULL = workspace prepared by the forward call */, float* dx, int lddx,
                         int B, int H, int W, int Cin, int Cout, int k, int stride,
                         void* workspace, size_t workspace_bytes, const unsigned* dy_amax /* mode 3, nullable */,
                         const float* residual, int ldr, void* stream);

@@ -179,3 +179,36 @@ def test_chain_and_resblock_through_planes_match_the_fp32_tensor_path(dev):
     assert float((gx1 - gx0).abs().max()) <= 2e-4 * float(gx0.abs().max())
     for a, b in zip(gp1, gp0):
         assert float((a - b).abs().max()) <= 2e-4 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 128, 3, 1, 12, True), (2, 128, 64, 3, 2, 13, False), (3, 256, 128, 1, 1, 9, True),
+                                  (2, 32, 64, 3, 1, 10, False), (2, 64, 32, 1, 1, 8, False)])
+def test_forward_call_prepares_the_dgrad_filter(dev, case):
+    """A training forward hands the backward pass of the same layer its transposed filter planes (one split launch for both,
+    y4_conv2d_fwd_bnstats_f32 / y4_conv2d_fwd_planes_f32 `dgrad_filter`): dgrad with that buffer and w == NULL must be
+    bit-identical to dgrad that splits the filter itself."""
+    from yolov4_amd import ops
+    B, ci, co, k, s, H, planes = case
+    x = cl(recipe.randn((B, ci, H, H), 21), dev)
+    w = cl(recipe.randn((co, ci, k, k), 22, 1.0 / np.sqrt(ci * k * k)), dev)
+    Ho = (H + 2 * ((k - 1) // 2) - k) // s + 1
+    dy = cl(recipe.randn((B, co, Ho, Ho), 23), dev)
+    buf = ops.dgrad_filter_buffer(ci, co, k, dev)
+    if planes:
+        xp = ops.planes_split_raw(x)
+        y_a = ops.conv_fwd_planes_raw(xp, w, k, s, stats=False)
+        y_b, _, _ = ops.conv_fwd_planes_raw(xp, w, k, s, dgrad_filter=buf)
+        dyp = ops.planes_split_raw(dy)
+        dx_a = ops.conv_dgrad_planes_raw(dyp, w, (B, ci, H, H), k)
+        dx_b = ops.conv_dgrad_planes_raw(dyp, w, (B, ci, H, H), k, prepared=buf)
+    else:
+        rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+        y_a, _, _ = ops.conv_fwd_bnstats_raw(x, w, k, s, rm, rv, None, 0.1, 1e-5)
+        y_b, _, _ = ops.conv_fwd_bnstats_raw(x, w, k, s, rm, rv, None, 0.1, 1e-5, dgrad_filter=buf)
+        dx_a = ops.conv_dgrad_raw(dy, w, (B, ci, H, H), k, s)
+        dx_b = ops.conv_dgrad_raw(dy, w, (B, ci, H, H), k, s, prepared=buf)
+    torch.cuda.synchronize()
+    assert torch.equal(y_a, y_b)
+    assert torch.equal(dx_a, dx_b)
+    ref = torch.nn.grad.conv2d_input((B, ci, H, H), w.double().cpu(), dy.double().cpu(), s, (k - 1) // 2)
+    assert float((dx_b.double().cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())

@@ -26,7 +26,7 @@ def test_convbnact_ctx_does_not_hold_its_output(monkeypatch):
     from yolov4_amd import ops
     from yolov4_amd.darknet.darknet import ConvBNAct
 
-    def fake_bnstats(x, w, k, s, rm, rv, nbt, mom, eps, x_amax=None):
+    def fake_bnstats(x, w, k, s, rm, rv, nbt, mom, eps, x_amax=None, dgrad_filter=None):
         y = torch.nn.functional.conv2d(x, w, None, s, (k - 1) // 2)
         return y, y.mean((0, 2, 3)), (y.var((0, 2, 3), unbiased=False) + eps).rsqrt()
 

@@ -1451,6 +1451,40 @@ __global__ __launch_bounds__(256) void f16x2_split_filter_folded_kernel(const fl
         planes[o + 32] = lo;
     }
 }
+// forward planes AND the transposed (dgrad) planes of one filter in one launch: a training forward prepares both, the
+// backward pass of the same layer then starts without its own maximum + split launches (the filter cannot change between the
+// two: autograd saved it).  Same element arithmetic as the two kernels below / above, one shared maximum.
+__global__ __launch_bounds__(256) void f16x2_split_filter_dual_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                                      unsigned short* __restrict__ planes_t, int Cout, int Cin, int kk,
+                                                                      int Cout_pad, const unsigned* __restrict__ part, int nparts,
+                                                                      unsigned* __restrict__ amax_out, unsigned* __restrict__ amax_out_t,
+                                                                      int mirror) {
+    const unsigned amax = amax_fold_partials(part, nparts, amax_out);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *amax_out_t = amax;
+    const float s = __uint_as_float(f16x2_scale_exp(amax) << 23);
+    const long long n = (long long)Cout * kk * Cin;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        unsigned short hi, lo;
+        split2(w[i], s, hi, lo);
+        const long long o = (i >> 5) * 64 + (i & 31);
+        planes[o] = hi;
+        planes[o + 32] = lo;
+    }
+    const long long total = (long long)Cin * kk * Cout_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int nn = (int)(i % Cout_pad);
+        const long long t = i / Cout_pad;
+        const int tp = (int)(t % kk);
+        const int tap = mirror ? kk - 1 - tp : tp;
+        const int c = (int)(t / kk);
+        const float v = nn < Cout ? w[((long long)nn * kk + tap) * Cin + c] : 0.0f;
+        unsigned short hi, lo;
+        split2(v, s, hi, lo);
+        const long long o = (i >> 5) * 64 + (i & 31);
+        planes_t[o] = hi;
+        planes_t[o + 32] = lo;
+    }
+}
 __global__ __launch_bounds__(256) void f16x2_transpose_split_filter_folded_kernel(const float* __restrict__ w,
                                                                                   unsigned short* __restrict__ planes, int Cout, int Cin,
                                                                                   int kk, int Cout_pad, const unsigned* __restrict__ part,
@@ -1732,6 +1766,21 @@ int f16x2_filter_planes(const float* w, unsigned short* planes, int Cout, int K,
     Y4_CHECK_LAUNCH();
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(f16x2_split_filter_folded_kernel, dim3(blocks), dim3(256), 0, st, w, planes, n, part, np, amax_out);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+int f16x2_filter_planes_dual(const float* w, unsigned short* planes, unsigned* amax_out, unsigned* part, unsigned short* planes_t,
+                             unsigned* amax_out_t, int Cout, int Cin, int kk, int Cout_pad, bool mirror, hipStream_t st) {
+    const long long n = (long long)Cout * kk * Cin;
+    const int np = filter_amax_partials(w, n, part, st);
+    if (np < 0) return Y4_ERR_SHAPE;
+    Y4_CHECK_LAUNCH();
+    const long long total = (long long)Cin * kk * Cout_pad;
+    const long long most = n > total ? n : total;
+    const int blocks = (int)((most + 255) / 256 > 4096 ? 4096 : (most + 255) / 256);
+    hipLaunchKernelGGL(f16x2_split_filter_dual_kernel, dim3(blocks), dim3(256), 0, st, w, planes, planes_t, Cout, Cin, kk, Cout_pad,
+                       part, np, amax_out, amax_out_t, mirror ? 1 : 0);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -56,6 +56,8 @@ int f16x2_refresh_prepared(const float* w, void* prepared, int Cout, int K, hipS
 // filter maximum + split in two launches without atomics or pre-zeroed words: per-block maxima into part[<= 1024], folded
 // by every block of the split kernel (block 0 leaves the result in *amax_out for the conv kernel's epilogue)
 int f16x2_filter_planes(const float* w, unsigned short* planes, int Cout, int K, unsigned* amax_out, unsigned* part, hipStream_t st);
+int f16x2_filter_planes_dual(const float* w, unsigned short* planes, unsigned* amax_out, unsigned* part, unsigned short* planes_t,
+                             unsigned* amax_out_t, int Cout, int Cin, int kk, int Cout_pad, bool mirror, hipStream_t st);
 int f16x2_filter_planes_transposed(const float* w, unsigned short* planes, int Cout, int Cin, int kk, int Cout_pad,
                                    unsigned* amax_out, unsigned* part, hipStream_t st, bool mirror = false);
 // conv_igemm.hip: dw[n] = sum over `splits` fp32 slabs of n elements each, fixed order (deterministic)

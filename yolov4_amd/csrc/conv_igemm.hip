@@ -1770,7 +1770,7 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
                          const float* scale, const float* shift, int act,
                          const float* residual, int ldr, float* stats, int* nparts, const unsigned* x_amax,
                          unsigned* y_amax, void* workspace, size_t workspace_bytes, void* stream,
-                         void* w_prepared = nullptr) {
+                         void* w_prepared = nullptr, void* dgrad_filter = nullptr, size_t dgrad_filter_bytes = 0) {
     if (!x || (!w && !w_prepared) || !y) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
@@ -1811,7 +1811,19 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
         unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + FWD_WS_HDR);
         g.wt_planes = planes;
         if (g_conv_mode == 3) {
-            int rc = y4::f16x2_filter_planes(w, planes, Cout, g.K, hdr, hdr + 16, y4_stream(stream));
+            int rc;
+            if (dgrad_filter) {
+                // the backward pass of this layer will want the transposed planes of the same filter: both in one launch,
+                // into a buffer laid out as y4_conv2d_dgrad_f32's workspace (which that call then takes with w == NULL)
+                if (dgrad_filter_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+                if (reinterpret_cast<uintptr_t>(dgrad_filter) & 15) return Y4_ERR_SHAPE;
+                const int cp = (Cout + 31) / 32 * 32;
+                unsigned* hdr_t = reinterpret_cast<unsigned*>(static_cast<char*>(dgrad_filter) + (size_t)Cin * k * k * cp * 6);
+                rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin,
+                                                  k * k, cp, false, y4_stream(stream));
+            } else {
+                rc = y4::f16x2_filter_planes(w, planes, Cout, g.K, hdr, hdr + 16, y4_stream(stream));
+            }
             if (rc != Y4_OK) return rc;
             if (!x_amax) {                                  // no producer-side maximum: one extra pass over the input
                 rc = y4::amax_launch(x, ldx, (long long)B * H * W, Cin, hdr + 1, y4_stream(stream));
@@ -1862,12 +1874,15 @@ size_t y4_conv2d_bnstats_workspace(int B, int H, int W, int Cin, int Cout, int k
 int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y, int ldy,
                               int B, int H, int W, int Cin, int Cout, int k, int stride,
                               float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
-                              void* workspace, size_t workspace_bytes, void* stream) {
+                              void* workspace, size_t workspace_bytes, void* dgrad_filter, size_t dgrad_filter_bytes,
+                              void* stream) {
     if (!partials || !nparts_host) return Y4_ERR_NULL;
+    if (dgrad_filter && g_conv_mode != 3) return Y4_ERR_SHAPE;
     if (partial_bytes < y4_conv2d_bnstats_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;
     int np = 0;
     const int rc = conv_fwd_impl(x, ldx, w, y, ldy, B, H, W, Cin, Cout, k, stride, nullptr, nullptr, Y4_ACT_LINEAR,
-                                 nullptr, 0, partials, &np, x_amax, nullptr, workspace, workspace_bytes, stream);
+                                 nullptr, 0, partials, &np, x_amax, nullptr, workspace, workspace_bytes, stream, nullptr,
+                                 dgrad_filter, dgrad_filter_bytes);
     if (rc != Y4_OK) return rc;
     *nparts_host = np;
     return Y4_OK;
@@ -1884,7 +1899,8 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
                            int B, int H, int W, int Cin, int Cout, int k, int stride,
                            void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                            const float* residual, int ldr, void* stream) {
-    if (!dy || !w || !dx || !workspace) return Y4_ERR_NULL;
+    if (!dy || !dx || !workspace) return Y4_ERR_NULL;
+    if (!w && g_conv_mode != 3) return Y4_ERR_NULL;        // w == NULL: the workspace already holds the transposed planes
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2))
         return Y4_ERR_SHAPE;
     const int Cout_pad = (Cout + 31) / 32 * 32;
@@ -1899,9 +1915,11 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)total * 6);
     unsigned* wamax = hdr;                                 // the call's own words: nothing shared between calls
     if (g_conv_mode == 3) {
-        const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad,
-                                                          wamax, hdr + 16, st);
-        if (rc != Y4_OK) return rc;
+        if (w) {
+            const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad,
+                                                              wamax, hdr + 16, st);
+            if (rc != Y4_OK) return rc;
+        }                                                  // else: left there by y4_conv2d_fwd_bnstats_f32(..., dgrad_filter)
     } else if (g_conv_mode != 0)
         hipLaunchKernelGGL(transpose_split_filter_kernel, dim3(blocks), dim3(256), 0, st, w,
                            static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad, g_conv_mode == 2 ? 1 : 3);

@@ -726,7 +726,8 @@ int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsig
 int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,
                              int B, int H, int W, int Cin, int Cout, int k, int stride,
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
-                             void* workspace, size_t workspace_bytes, void* stream) {
+                             void* workspace, size_t workspace_bytes, void* dgrad_filter, size_t dgrad_filter_bytes,
+                             void* stream) {
     if (!x_planes || !w || !y || !x_amax || !workspace) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cin, Cout, k, stride) || ldy < Cout || (ldy & 3)) return Y4_ERR_SHAPE;
     if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
@@ -739,7 +740,18 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
     hipStream_t st = y4_stream(stream);
     unsigned* hdr = static_cast<unsigned*>(workspace);
     unsigned short* planes = reinterpret_cast<unsigned short*>(static_cast<char*>(workspace) + 64 + 4096);
-    int rc = y4::f16x2_filter_planes(w, planes, Cout, k * k * Cin, hdr, hdr + 16, st);
+    int rc;
+    if (dgrad_filter) {
+        // also the mirrored transposed planes for y4_conv2d_dgrad_planes_f32 (which then takes them with w == NULL): one launch
+        if (stride != 1 || (Cout & 31)) return Y4_ERR_SHAPE;
+        if (dgrad_filter_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+        if (reinterpret_cast<uintptr_t>(dgrad_filter) & 15) return Y4_ERR_SHAPE;
+        unsigned* hdr_t = reinterpret_cast<unsigned*>(static_cast<char*>(dgrad_filter) + (size_t)Cin * k * k * Cout * 6);
+        rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin, k * k,
+                                          Cout, true, st);
+    } else {
+        rc = y4::f16x2_filter_planes(w, planes, Cout, k * k * Cin, hdr, hdr + 16, st);
+    }
     if (rc != Y4_OK) return rc;
     int np = 0;
     rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, nullptr, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st);
@@ -753,7 +765,7 @@ int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx,
                                int B, int H, int W, int Cin, int Cout, int k,
                                void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                                const float* residual, int ldr, void* stream) {
-    if (!dy_planes || !w || !dx || !dy_amax || !workspace) return Y4_ERR_NULL;
+    if (!dy_planes || !dx || !dy_amax || !workspace) return Y4_ERR_NULL;     // w == NULL: workspace filled by the forward call
     if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cout, Cin, k, 1) || lddx < Cin || (lddx & 3)) return Y4_ERR_SHAPE;
     if (residual && (ldr < Cin || (ldr & 3) || (reinterpret_cast<uintptr_t>(residual) & 15))) return Y4_ERR_SHAPE;
     if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
@@ -763,8 +775,10 @@ int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx,
     hipStream_t st = y4_stream(stream);
     const long long total = (long long)Cin * k * k * Cout;
     unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)total * 6);
-    int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout, hdr, hdr + 16, st, true);
-    if (rc != Y4_OK) return rc;
+    if (w) {
+        const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout, hdr, hdr + 16, st, true);
+        if (rc != Y4_OK) return rc;
+    }
     return y4::planes_conv(dy_planes, dy_amax, workspace, hdr, dx, lddx, residual, ldr, nullptr, nullptr, B, H, W, Cout, Cin, k, 1, st);
 }
 

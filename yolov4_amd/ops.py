@@ -265,7 +265,13 @@ def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None
     return out
 
 
-def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, eps, x_amax=None):
+def dgrad_filter_buffer(Cin, Cout, k, device):
+    """Buffer a training forward call fills with the transposed filter planes for the backward pass of the same layer (one
+    split launch serves both; the dgrad call takes it as its workspace and launches no filter kernels)."""
+    return _ws(lib().y4_conv2d_dgrad_workspace(Cin, Cout, k), device)
+
+
+def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, eps, x_amax=None, dgrad_filter=None):
     """Training-mode conv: raw output y + BatchNorm batch statistics taken in the conv epilogue
     (per-M-tile column sums, folded in fp64 by a second-stage kernel).  Returns (y, mean, invstd)."""
     L = lib()
@@ -297,7 +303,8 @@ def conv_fwd_bnstats_raw(x, w, k, s, running_mean, running_var, nbt, momentum, e
         nbytes = L.y4_conv2d_fwd_workspace(Cin, Cout, k)
         cws = _ws(nbytes, x.device)
         check(L.y4_conv2d_fwd_bnstats_f32(_ptr(x), ldx, _ptr(w), _ptr(y), ldy, B, H, W, Cin, Cout, k, s,
-                                          _ptr(part), pbytes, ctypes.byref(n), _ptr(x_amax), _ptr(cws), nbytes, _stream()),
+                                          _ptr(part), pbytes, ctypes.byref(n), _ptr(x_amax), _ptr(cws), nbytes,
+                                          _ptr(dgrad_filter), dgrad_filter.numel() if dgrad_filter is not None else 0, _stream()),
               'conv2d_fwd_bnstats')
         nparts = n.value
     mean = torch.empty(Cout, device=x.device, dtype=torch.float32)
@@ -334,7 +341,7 @@ def planes_split_raw(x, amax=None):
     return Planes(buf, (B, C, H, W), amax)
 
 
-def conv_fwd_planes_raw(xp, w, k, s, stats=True):
+def conv_fwd_planes_raw(xp, w, k, s, stats=True, dgrad_filter=None):
     """Training-mode conv over a Planes input: raw output y (+ per-M-tile column sums, n_tiles)."""
     L = lib()
     B, Cin, H, W = xp.shape
@@ -348,15 +355,16 @@ def conv_fwd_planes_raw(xp, w, k, s, stats=True):
     part = _ws(pbytes, xp.buf.device) if stats else None
     n = ctypes.c_longlong(0)
     check(L.y4_conv2d_fwd_planes_f32(_ptr(xp.buf), _ptr(w), _ptr(y), nhwc_pitch(y), B, H, W, Cin, Cout, k, s,
-                                     _ptr(part), pbytes, ctypes.byref(n), _ptr(xp.amax), _ptr(ws), nbytes, _stream()),
+                                     _ptr(part), pbytes, ctypes.byref(n), _ptr(xp.amax), _ptr(ws), nbytes,
+                                     _ptr(dgrad_filter), dgrad_filter.numel() if dgrad_filter is not None else 0, _stream()),
           'conv2d_fwd_planes')
     return (y, part, n.value) if stats else y
 
 
-def conv_fwd_planes_bnstats_raw(xp, w, k, s, running_mean, running_var, nbt, momentum, eps):
+def conv_fwd_planes_bnstats_raw(xp, w, k, s, running_mean, running_var, nbt, momentum, eps, dgrad_filter=None):
     """conv_fwd_bnstats_raw over a Planes input: (y, mean, invstd)."""
     L = lib()
-    y, part, nparts = conv_fwd_planes_raw(xp, w, k, s)
+    y, part, nparts = conv_fwd_planes_raw(xp, w, k, s, dgrad_filter=dgrad_filter)
     Cout = w.shape[0]
     M = y.shape[0] * y.shape[2] * y.shape[3]
     mean = torch.empty(Cout, device=y.device, dtype=torch.float32)
@@ -376,18 +384,18 @@ def planes_of(t):
     return Planes(t, t.shape, t.y4_amax)
 
 
-def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None):
+def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None, prepared=None):
     """dx of a stride-1 conv from a Planes dy (the DMA forward kernel on the mirrored transposed filter)."""
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
     dx = empty_nhwc(B, Cin, H, W, dyp.buf.device)
     nbytes = L.y4_conv2d_dgrad_workspace(Cin, Cout, k)
-    ws = _ws(nbytes, dyp.buf.device)
+    ws = prepared if prepared is not None else _ws(nbytes, dyp.buf.device)     # prepared: filled by the forward call
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual)
-    check(L.y4_conv2d_dgrad_planes_f32(_ptr(dyp.buf), _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k,
+    check(L.y4_conv2d_dgrad_planes_f32(_ptr(dyp.buf), None if prepared is not None else _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k,
                                        _ptr(ws), nbytes, _ptr(dyp.amax), _ptr(residual), ldr, _stream()), 'conv2d_dgrad_planes')
     return dx
 
@@ -430,7 +438,7 @@ def last_conv_kernel():
     return buf.value.decode()
 
 
-def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None):
+def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None, prepared=None):
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
@@ -447,11 +455,11 @@ def conv_dgrad_raw(dy, w, x_shape, k, s, dy_amax=None, residual=None):
     dy, lddy = as_nhwc(dy, min_pitch=cpad)
     dx = empty_nhwc(B, Cin, H, W, dy.device)
     nbytes = L.y4_conv2d_dgrad_workspace(Cin, Cout, k)
-    ws = _ws(nbytes, dy.device)
+    ws = prepared if prepared is not None else _ws(nbytes, dy.device)          # prepared: filled by the forward call (mode 3)
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual, need_vec4=False)
-    check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
+    check(L.y4_conv2d_dgrad_f32(_ptr(dy), lddy, None if prepared is not None else _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k, s,
                                 _ptr(ws), nbytes, _ptr(dy_amax), _ptr(residual), ldr, _stream()),
           'conv2d_dgrad')
     return dx
@@ -725,12 +733,18 @@ class ConvBNActFn(torch.autograd.Function):
         if bn and training:
             if x.shape[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[0] * conv_out_hw(x.shape[2], x.shape[3], k, s)[1] <= 1:
                 raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
+            # the backward pass wants the transposed planes of the same filter: the forward split launch writes both
+            ctx.dgrad_filter = None
+            if (f16 and ctx.needs_input_grad[0] and x.shape[1] % 32 == 0 and fast_conv_shape(x.shape[1], k, s)
+                    and weight.shape[0] % 4 == 0 and (xp is None or weight.shape[0] % 32 == 0)):
+                ctx.dgrad_filter = dgrad_filter_buffer(x.shape[1], weight.shape[0], k, x.device)
             if xp is not None:
                 y, mean, invstd = conv_fwd_planes_bnstats_raw(xp, weight, k, s, cfg['running_mean'], cfg['running_var'],
-                                                              cfg['nbt'], cfg['momentum'], cfg['eps'])
+                                                              cfg['nbt'], cfg['momentum'], cfg['eps'], dgrad_filter=ctx.dgrad_filter)
             else:
                 y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
-                                                       cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax)
+                                                       cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax,
+                                                       dgrad_filter=ctx.dgrad_filter)
             want = cfg.get('out_planes')
             if want and f16 and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
                 z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest if want == 'both' else None,
@@ -836,9 +850,12 @@ class ConvBNActFn(torch.autograd.Function):
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
             elif x_planes:
-                dx = conv_dgrad_planes_raw(Planes(dy, dy.shape, dy_amax), weight, ctx.x_shape, k, residual=skip_grad)
+                dx = conv_dgrad_planes_raw(Planes(dy, dy.shape, dy_amax), weight, ctx.x_shape, k, residual=skip_grad,
+                                           prepared=getattr(ctx, 'dgrad_filter', None))
             else:
-                dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad)
+                dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad,
+                                    prepared=getattr(ctx, 'dgrad_filter', None) if f16x2_mode() else None)
+            ctx.dgrad_filter = None
         elif skip_grad is not None:
             raise Y4Error('a parked skip gradient has no consumer (input of the 1x1 conv does not require grad)')
         dw = None
