@@ -182,11 +182,21 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
             fb[j][0] = *reinterpret_cast<const f16x8*>(base + b_hi + j * 16 * PROW);
             fb[j][1] = *reinterpret_cast<const f16x8*>(base + b_lo + j * 16 * PROW);
         }
+        // A fragments one row tile ahead: those of row tile i + 1 are requested BEFORE the MFMAs of row tile i, so the LDS
+        // round trip runs under 12 MFMAs (+2-4 % on the 3x3 layers, A/B on one box); the scheduling barrier keeps the MFMAs
+        // of row tile TM - 2 in front of the waits (the compiler otherwise sinks them below the barrier)
+        f16x8 fap[2][2];
+        fap[0][0] = *reinterpret_cast<const f16x8*>(base + a_hi);
+        fap[0][1] = *reinterpret_cast<const f16x8*>(base + a_lo);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const f16x8 fa0 = *reinterpret_cast<const f16x8*>(base + a_hi + i * 16 * PROW);
-            const f16x8 fa1 = *reinterpret_cast<const f16x8*>(base + a_lo + i * 16 * PROW);
+            if (i + 1 < TM) {
+                fap[(i + 1) & 1][0] = *reinterpret_cast<const f16x8*>(base + a_hi + (i + 1) * 16 * PROW);
+                fap[(i + 1) & 1][1] = *reinterpret_cast<const f16x8*>(base + a_lo + (i + 1) * 16 * PROW);
+            }
+            const f16x8 fa0 = fap[i & 1][0], fa1 = fap[i & 1][1];
             if (i == TM - 1) {
+                __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every read of stage S has returned
                 if (kt + 1 < KT) {
                     if constexpr (NSTAGE == 3) {
@@ -492,11 +502,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
             fb[j][0] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[0 + (j & 1)]);
             fb[j][1] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[2 + (j & 1)]);
         }
+        f16x8 fap[2][2];                                   // one row tile ahead, as in conv_planes_mfma
+        fap[0][0] = tr_frag(base + a_tile0 + segoff[0]);
+        fap[0][1] = tr_frag(base + a_tile0 + segoff[2]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const f16x8 fa0 = tr_frag(base + a_tile0 + (i >> 1) * 32 * PROW + segoff[0 + (i & 1)]);
-            const f16x8 fa1 = tr_frag(base + a_tile0 + (i >> 1) * 32 * PROW + segoff[2 + (i & 1)]);
+            if (i + 1 < TM) {
+                fap[(i + 1) & 1][0] = tr_frag(base + a_tile0 + ((i + 1) >> 1) * 32 * PROW + segoff[0 + ((i + 1) & 1)]);
+                fap[(i + 1) & 1][1] = tr_frag(base + a_tile0 + ((i + 1) >> 1) * 32 * PROW + segoff[2 + ((i + 1) & 1)]);
+            }
+            const f16x8 fa0 = fap[i & 1][0], fa1 = fap[i & 1][1];
             if (i == TM - 1) {
+                __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (kt + 1 < KT) {
                     if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
