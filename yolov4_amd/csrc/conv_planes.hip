@@ -203,6 +203,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                         if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
+                        // (all six at once here is 3-5 % SLOWER on the 3x3 layers, measured: this kernel's pieces mostly hit L2)
                         if (kt + 3 < KT) { issue(S, I0{}, I2{}); pend = true; }
                     } else {
                         // two stages: only tile t + 1 is in flight (issued one whole step ago); the other block on this CU
@@ -368,6 +369,7 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* p) {      // k 0..
 template <int TN_, int TJ_>
 __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom g) {
     constexpr int NWAVE = 8, WN2 = 2, WJ = 4;
+    constexpr int BAR = 2;                                 // row tile in front of whose MFMAs the barrier sits (see `step`)
     constexpr int WTN = TN_ / WN2, WTJ = TJ_ / WJ, TM = WTN / 16, TN = WTJ / 16;
     static_assert(TM == 4 && TN == 4, "wave tile 64 x 64");
     constexpr int A_BYTES = (TN_ / 32) * 32 * PROW, B_BYTES = (TJ_ / 32) * 32 * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
     // x pieces: pixel octet wave & 3, j chunks (wave >> 2) * 4 + i: ONE pixel per lane, four taps / channel chunks
     const int xp = (wave & 3) * 8 + lr;                    // pixel of this lane inside the K-step
     unsigned x_const[PB];                                  // tap offset + channel chunk + swizzled position; OOB: chunk beyond J
-    int x_dh[PB], x_dw[PB];
+    unsigned x_pk = 0u;                                    // per piece 8 bits: (dh + 2) | (dw + 2) << 4; dh + 2 = 15: never valid
     {
         const int gsw = ((xp >> 1) & 1) | (((xp >> 3) & 1) << 1);
         const unsigned srcoff = (unsigned)((((pos >> 1) ^ gsw) << 5) + ((pos & 1) << 4));
@@ -431,18 +433,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
             const int tap = ok ? jg / CC : 0;
             const int c32 = jg - tap * CC;
             const int r = tap / g.k, q = tap - r * g.k;
-            x_dh[i] = ok ? r - g.pad : (1 << 20);          // (an impossible row: never valid)
-            x_dw[i] = q - g.pad;
+            x_pk |= (unsigned)((ok ? r - g.pad + 2 : 15) | ((q - g.pad + 2) << 4)) << (8 * i);
             x_const[i] = (unsigned)((long long)(P0 - Pw) * pitch_x) + (unsigned)(((r - g.pad) * g.W + (q - g.pad)) * (int)pitch_x) +
                          (unsigned)c32 * 128u + srcoff;
         }
     }
     // running raster position of this lane's pixel of the NEXT K-step to be issued
-    long long lp = P0 + xp;
+    int lp = (int)P0 + xp;                                 // (M < 2^31, checked on the host; may run past M by < 2^12)
     int lh, lw;
     {
         const long long hw = (long long)g.H * g.W;
-        const long long rem = lp % hw;
+        const long long rem = (long long)lp % hw;
         lh = (int)(rem / g.W); lw = (int)(rem - (long long)lh * g.W);
     }
     unsigned lbase = (unsigned)xp * pitch_x;               // (pixel - P0) * pitch, mod 2^32
@@ -458,7 +459,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(dy_rsrc, (lds_ptr)(st + (wave * PA + p) * 1024), 16, (int)vo, 0, 0, 0);
             } else {
                 const int i = p - PA;
-                const bool ok = lp < g.M && (unsigned)(lh + x_dh[i]) < (unsigned)g.H && (unsigned)(lw + x_dw[i]) < (unsigned)g.W;
+                const int dh = (int)((x_pk >> (8 * i)) & 15u) - 2, dw = (int)((x_pk >> (8 * i + 4)) & 15u) - 2;
+                const bool ok = lp < g.M && (unsigned)(lh + dh) < (unsigned)g.H && (unsigned)(lw + dw) < (unsigned)g.W;
                 const unsigned vo = ok ? lbase + x_const[i] : OOB;
                 const int b = ((wave >> 2) * PB + i) * 4 + (wave & 3);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(st + A_BYTES + b * 1024), 16, (int)vo, 0, 0, 0);
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
             while (lw >= g.W) { lw -= g.W; if (++lh == g.H) lh = 0; }
         }
     };
-    using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
+    using I0 = std::integral_constant<int, 0>;
     using I6 = std::integral_constant<int, NDMA>;          // (= all pieces of a K-tile)
 
     accv acc0[TM][TN], acc1[TM][TN];
@@ -492,7 +494,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
     const int a_tile0 = (wn2 * (WTN / 32)) * 32 * PROW;                // chunk of this wave's first n tile
     const int b_tile0 = A_BYTES + (wj * (WTJ / 32)) * 32 * PROW;
 
-    bool pend = false;
     auto step = [&](auto SC, const int kt) {
         constexpr int S = decltype(SC)::value;
         const unsigned char* base = smem + S * STAGE;
@@ -502,24 +503,32 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
             fb[j][0] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[0 + (j & 1)]);
             fb[j][1] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[2 + (j & 1)]);
         }
-        f16x8 fap[2][2];                                   // one row tile ahead, as in conv_planes_mfma
+        // A fragments ahead of their MFMAs: row tile i + 1 is requested before the MFMAs of row tile i; at the barrier
+        // position BAR everything still missing is requested, so that the stage goes back to the DMA 24 MFMAs before the step
+        // ends (BAR = 3 -> 2: +5...9 %; BAR = 1 or 0 need three / four fragment sets live and spill inside the loop: 1.6x slower)
+        f16x8 fap[TM][2];
         fap[0][0] = tr_frag(base + a_tile0 + segoff[0]);
         fap[0][1] = tr_frag(base + a_tile0 + segoff[2]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            if (i + 1 < TM) {
-                fap[(i + 1) & 1][0] = tr_frag(base + a_tile0 + ((i + 1) >> 1) * 32 * PROW + segoff[0 + ((i + 1) & 1)]);
-                fap[(i + 1) & 1][1] = tr_frag(base + a_tile0 + ((i + 1) >> 1) * 32 * PROW + segoff[2 + ((i + 1) & 1)]);
-            }
-            const f16x8 fa0 = fap[i & 1][0], fa1 = fap[i & 1][1];
-            if (i == TM - 1) {
+#pragma unroll
+            for (int r = i + 1; r < TM; ++r)
+                if ((i < BAR && r == i + 1) || (i == BAR && r > i)) {
+                    fap[r][0] = tr_frag(base + a_tile0 + (r >> 1) * 32 * PROW + segoff[0 + (r & 1)]);
+                    fap[r][1] = tr_frag(base + a_tile0 + (r >> 1) * 32 * PROW + segoff[2 + (r & 1)]);
+                }
+            const f16x8 fa0 = fap[i][0], fa1 = fap[i][1];
+            if (i == BAR) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (kt + 1 < KT) {
                     if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    if (kt + 3 < KT) { issue(S, I0{}, I2{}); pend = true; }
+                    // all six pieces of tile t + 3 at once, the moment its stage is free: this kernel streams fresh pixels every
+                    // K-step and waits for them (with the DMA switched off it runs 1.4-1.8x faster), so two whole steps of lead
+                    // beat spreading the issues between the MFMA groups (+3...27 %, 12 % on average, A/B on one box)
+                    if (kt + 3 < KT) issue(S, I0{}, I6{});
                 }
             }
 #pragma unroll
@@ -528,8 +537,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
                 acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
                 acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
             }
-            if (i == 0 && pend) issue((S + 2) % NSTAGE, I2{}, I4{});
-            if (i == 1 && pend) { issue((S + 2) % NSTAGE, I4{}, I6{}); pend = false; }
         }
     };
 
@@ -556,7 +563,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
     constexpr int EP = WTJ + 4;
     static_assert(NWAVE * WTN * EP * 4 <= NSTAGE * STAGE, "epilogue patches must fit the stages");
     float* patch = reinterpret_cast<float*>(smem) + wave * (WTN * EP);
-    const int fr = lane & 15, kq = lane >> 4;
+    // the epilogue's lane arithmetic starts from an opaque copy of the lane id: otherwise the compiler forms these addresses
+    // before the K loop, where every one of the 256 registers is taken, and parks them in scratch
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int fr = lane_e & 15, kq = lane_e >> 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -564,11 +575,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
 #pragma unroll
             for (int e = 0; e < 4; ++e) patch[(i * 16 + 4 * kq + e) * EP + j * 16 + fr] = acc0[i][j][e] * un + acc1[i][j][e] * un1;
     float* out = g.out + (long long)split * g.Cout * g.J;
-    const int c4 = (lane & 15) * 4;
+    const int c4 = (lane_e & 15) * 4;
     const int jv = j0 + wj * WTJ + c4;
 #pragma unroll
     for (int it = 0; it < WTN / 4; ++it) {
-        const int row = it * 4 + (lane >> 4);
+        const int row = it * 4 + (lane_e >> 4);
         const int n = n0 + wn2 * WTN + row;
         if (n < g.Cout && jv < g.J)
             *reinterpret_cast<f32x4v*>(out + (long long)n * g.J + jv) = *reinterpret_cast<const f32x4v*>(patch + row * EP + c4);
@@ -688,7 +699,7 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     g.x = static_cast<const unsigned char*>(x); g.dy = static_cast<const unsigned char*>(dy);
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.pad = (k - 1) / 2;
     const long long M = (long long)B * H * W;
-    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
+    if (M >= (1ll << 31) - 65536) return Y4_ERR_SHAPE;     // (32-bit pixel counters in the kernel, with room for a K-step past M)
     g.M = (int)M; g.J = k * k * Cin;
     planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split);
     g.x_total_bytes = (unsigned long long)M * Cin * 4ull;
