@@ -15,7 +15,7 @@ from kernel_resources import kernel_resources  # noqa: E402
 CSRC = os.path.join(ROOT, 'yolov4_amd', 'csrc')
 
 
-@pytest.mark.parametrize('src,flags', [('conv_f16x2.hip', ()), ('conv_planes.hip', ()), ('pointwise.hip', ()),
+@pytest.mark.parametrize('src,flags', [('conv_f16x2.hip', ()), ('conv_planes.hip', ()), ('conv_tile.hip', ()), ('pointwise.hip', ()),
                                         ('yolo_head.hip', ('-ffp-contract=off',))])
 def test_no_kernel_uses_scratch(src, flags):
     path = os.path.join(CSRC, src)

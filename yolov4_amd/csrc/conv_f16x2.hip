@@ -1713,6 +1713,9 @@ int f16x2_shape() {
 namespace y4 {
 
 int f16x2_gather(const ConvGeom& g, bool transposed, hipStream_t st, int* nparts) {
+    if (!transposed && !g.scale && !g.shift && !g.dst_amax && g.act == Y4_ACT_LINEAR && g.pad == 1 &&
+        tile_conv_ok(g.Cs, g.Cs_valid, g.N, g.k, g.stride, g.Hs, g.Ws))
+        return f16x2_tile(g, st, nparts);
     if (stream1x1_f16x2_ok(g)) return dispatch_stream1x1_f16x2(g, st, nparts);
     if (halo_ok(g)) {
         if (f16x2_shape() == 16) return transposed ? launch_halo_f16x2<true, 16>(g, st, nparts) : launch_halo_f16x2<false, 16>(g, st, nparts);

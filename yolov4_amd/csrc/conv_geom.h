@@ -67,6 +67,11 @@ int amax_launch(const float* x, long long ld, long long M, int C, unsigned* amax
 int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st);
 
 
+// conv_tile.hip: 3x3 stride-1 layers with few channels on large maps (2-D tiles, every input element staged once);
+// forward form only: dgrad hands in the mirrored transposed filter planes
+bool tile_conv_ok(int Cs, int Cs_valid, int N, int k, int stride, int H, int W);
+int f16x2_tile(const ConvGeom& g, hipStream_t st, int* nparts);
+
 // conv_planes.hip: DMA-fed kernels over pre-split operands
 bool planes_conv_ok(int Cin, int Cout, int k, int stride);
 int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,

@@ -1819,8 +1819,9 @@ static int conv_fwd_impl(const float* x, int ldx, const float* w, float* y, int 
                 if (reinterpret_cast<uintptr_t>(dgrad_filter) & 15) return Y4_ERR_SHAPE;
                 const int cp = (Cout + 31) / 32 * 32;
                 unsigned* hdr_t = reinterpret_cast<unsigned*>(static_cast<char*>(dgrad_filter) + (size_t)Cin * k * k * cp * 6);
+                // (the 2-D tile kernel runs dgrad in forward form: it wants the taps mirrored; same test as in conv_dgrad_impl)
                 rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin,
-                                                  k * k, cp, false, y4_stream(stream));
+                                                  k * k, cp, y4::tile_conv_ok(cp, Cout, Cin, k, stride, H, W), y4_stream(stream));
             } else {
                 rc = y4::f16x2_filter_planes(w, planes, Cout, g.K, hdr, hdr + 16, y4_stream(stream));
             }
@@ -1917,7 +1918,7 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
     if (g_conv_mode == 3) {
         if (w) {
             const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout_pad,
-                                                              wamax, hdr + 16, st);
+                                                              wamax, hdr + 16, st, y4::tile_conv_ok(Cout_pad, Cout, Cin, k, stride, H, W));
             if (rc != Y4_OK) return rc;
         }                                                  // else: left there by y4_conv2d_fwd_bnstats_f32(..., dgrad_filter)
     } else if (g_conv_mode != 0)
@@ -1948,6 +1949,8 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
             dy_amax = hdr + 1;
         }
         g.src_amax = dy_amax; g.wt_amax = wamax;
+        // few channels on a large map: the 2-D tile kernel, in forward form on the mirrored transposed planes (above)
+        if (y4::tile_conv_ok(Cout_pad, Cout, Cin, k, stride, H, W)) return y4::f16x2_tile(g, st, nullptr);
         return y4::f16x2_gather(g, true, st, nullptr);
     }
     return dispatch_gather<true>(g, st);
