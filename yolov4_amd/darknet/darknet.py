@@ -9,6 +9,8 @@ sequence instead: implicit-GEMM conv (MFMA) -> batch statistics -> normalise +
 activation (+ ResBlock skip), or in eval mode a single conv kernel with the
 folded BatchNorm, activation and skip in its epilogue.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -115,13 +117,18 @@ def chain(seq, x, last=False):
     return x
 
 
-def res_unit(pair, x):
+def res_unit(pair, x, out_planes=False):
     """x + conv3x3(conv1x1(x)) (darknet.py:76-80): the skip is added in the 3x3's BN+act kernel; in backward the gradient
     arriving over the skip is parked by the 3x3 and added in the 1x1's dgrad epilogue, so neither direction spends a
-    separate elementwise pass."""
+    separate elementwise pass.  out_planes: as ConvBNAct.forward, for the unit's result."""
     xa, xb = ops.fork(x)
     box = {} if (torch.is_grad_enabled() and xa.requires_grad and pair[0].training) else None
-    return pair[1](pair[0](xa, dres_take=box, out_planes=takes_planes(pair[1])), residual=xb, dres_put=box)
+    return pair[1](pair[0](xa, dres_take=box, out_planes=takes_planes(pair[1])), residual=xb, dres_put=box, out_planes=out_planes)
+
+
+# A residual unit's result feeds the next unit's 1x1 conv AND its skip: fp32 for the skip plus a pre-split twin for the conv
+# ('both') puts those 1x1 convs on the plane kernels at the price of one more 4-B/element write per unit (Y4_TWIN_RES=0: off)
+_TWIN_RES = os.environ.get('Y4_TWIN_RES', '1') != '0'
 
 
 class ResBlock(nn.Module):
@@ -133,13 +140,22 @@ class ResBlock(nn.Module):
             nn.Sequential(ConvBNAct(ch, ch, 1, 1, act=act), ConvBNAct(ch, ch, 3, 1, act=act))
             for _ in range(num_blocks))
 
-    def forward(self, x):
-        for pair in self.module_list:
+    def forward(self, x, out_planes=False):
+        """out_planes: for the block's result (the reference's forward has no such argument)."""
+        n = len(self.module_list)
+        for i, pair in enumerate(self.module_list):
             if self.shortcut:
-                x = res_unit(pair, x)
+                if i + 1 < n:
+                    want = 'both' if (_TWIN_RES and takes_planes(self.module_list[i + 1][0])) else False
+                else:
+                    want = out_planes
+                x = res_unit(pair, x, out_planes=want)
             else:
                 x = pair[1](pair[0](x))
         return x
+
+    def first_takes_planes(self):
+        return _TWIN_RES and takes_planes(self.module_list[0][0])
 
 
 class CSPDownSample0(nn.Module):
@@ -178,5 +194,9 @@ class CSPDownSample(nn.Module):
         xa, xb = ops.fork(self.base(x))
         cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels])
         x1 = self.part1(xa, out=cb.slot(1))
-        x2 = self.part2[2](self.part2[1](self.part2[0](xb)), out=cb.slot(0))
+        blk = self.part2[1]
+        # part2[0]'s result feeds the first unit's 1x1 conv and its skip; the block's result feeds part2[2] alone
+        first = 'both' if (blk.shortcut and blk.first_takes_planes()) else False
+        x2 = blk(self.part2[0](xb, out_planes=first), out_planes=blk.shortcut and _TWIN_RES and takes_planes(self.part2[2]))
+        x2 = self.part2[2](x2, out=cb.slot(0))
         return self.transition(ops.cat([x2, x1], into=cb))
