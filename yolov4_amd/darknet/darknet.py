@@ -191,7 +191,9 @@ class CSPDownSample(nn.Module):
         self.transition = ConvBNAct(out_ch, out_ch, 1, 1, act=act)
 
     def forward(self, x):
-        xa, xb = ops.fork(self.base(x))
+        # both consumers of the stride-2 conv's result are 1x1 convs: where both take planes the result leaves pre-split only
+        both = _TWIN_RES and takes_planes(self.part1) and takes_planes(self.part2[0])
+        xa, xb = ops.fork(self.base(x, out_planes=both))
         cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels])
         x1 = self.part1(xa, out=cb.slot(1))
         blk = self.part2[1]

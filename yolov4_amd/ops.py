@@ -917,6 +917,9 @@ def fork(x):
     twin = getattr(x, 'y4_twin', None)
     if twin is not None:
         a.y4_twin = b.y4_twin = twin
+    if getattr(x, 'y4_planes', False):               # a pre-split tensor read by two plane-taking convs (CSP split convs)
+        a.y4_planes = b.y4_planes = True
+        return tag_amax(a, x.y4_amax), tag_amax(b, x.y4_amax)
     return tag_amax(a, cell), tag_amax(b, cell)
 
 
