@@ -84,3 +84,29 @@ def test_tile_kernel_is_deterministic_and_image_independent(dev):
     one = ops.conv_fwd_raw(xd[2:3].contiguous(memory_format=torch.channels_last), wd, 3, 1, x_amax=amax)
     full = ops.conv_fwd_raw(xd, wd, 3, 1, x_amax=amax)
     assert torch.equal(one[0], full[2])
+
+
+@pytest.mark.parametrize('case', [(2, 32, 64, 208, 216), (1, 32, 64, 207, 215), (65, 32, 64, 200, 200)])
+def test_tile_kernel_stride2_dgrad(dev, case):
+    """dgrad of a 3x3 / stride-2 conv with 64 output channels (32 -> 64 @608 in the model): one staged dy patch per tile feeds
+    all four parity classes of the output.  Even and odd input sizes, more tiles than one round of blocks."""
+    from yolov4_amd import ops
+    B, ci, co, H, W = case
+    w = recipe.randn((co, ci, 3, 3), 52, 1.0 / np.sqrt(ci * 9))
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    dy = recipe.randn((B, co, Ho, Wo), 53)
+    wd, dyd = cl(w, dev), cl(dy, dev)
+    dx = ops.conv_dgrad_raw(dyd, wd, (B, ci, H, W), 3, 2)
+    assert ops.last_conv_kernel().startswith('conv3x3_tile_f16x2<64, 32, 16, true>'), ops.last_conv_kernel()
+    ref = torch.nn.grad.conv2d_input((B, ci, H, W), w.double(), dy.double(), 2, 1)
+    err = float((dx.double().cpu() - ref).abs().max())
+    assert err <= 1e-5 * float(ref.abs().max()), err
+    res = cl(recipe.randn((B, ci, H, W), 54), dev)
+    dx2 = ops.conv_dgrad_raw(dyd, wd, (B, ci, H, W), 3, 2, residual=res)
+    assert float((dx2 - (dx + res)).abs().max()) <= 1e-6 * float(ref.abs().max())
+    # prepared by the forward call
+    x = cl(recipe.randn((B, ci, H, W), 55), dev)
+    buf = ops.dgrad_filter_buffer(ci, co, 3, dev)
+    rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
+    ops.conv_fwd_bnstats_raw(x, wd, 3, 2, rm, rv, None, 0.1, 1e-5, dgrad_filter=buf)
+    assert torch.equal(ops.conv_dgrad_raw(dyd, wd, (B, ci, H, W), 3, 2, prepared=buf), dx)

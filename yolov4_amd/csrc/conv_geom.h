@@ -71,6 +71,8 @@ int amax_merge(unsigned* dst, const unsigned* src, hipStream_t st);
 // forward form only: dgrad hands in the mirrored transposed filter planes
 bool tile_conv_ok(int Cs, int Cs_valid, int N, int k, int stride, int H, int W);
 int f16x2_tile(const ConvGeom& g, hipStream_t st, int* nparts);
+bool tile_dgrad_s2_ok(int Cs, int Cs_valid, int N, int k, int stride, int Hs, int Ws);
+int f16x2_tile_dgrad_s2(const ConvGeom& g, hipStream_t st);      // dgrad of a stride-2 3x3 conv, all four parity classes per tile
 
 // conv_planes.hip: DMA-fed kernels over pre-split operands
 bool planes_conv_ok(int Cin, int Cout, int k, int stride);

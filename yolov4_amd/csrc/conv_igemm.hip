@@ -1951,6 +1951,7 @@ static int conv_dgrad_impl(const float* dy, int lddy, const float* w, float* dx,
         g.src_amax = dy_amax; g.wt_amax = wamax;
         // few channels on a large map: the 2-D tile kernel, in forward form on the mirrored transposed planes (above)
         if (y4::tile_conv_ok(Cout_pad, Cout, Cin, k, stride, H, W)) return y4::f16x2_tile(g, st, nullptr);
+        if (y4::tile_dgrad_s2_ok(Cout_pad, Cout, Cin, k, stride, g.Hs, g.Ws)) return y4::f16x2_tile_dgrad_s2(g, st);
         return y4::f16x2_gather(g, true, st, nullptr);
     }
     return dispatch_gather<true>(g, st);

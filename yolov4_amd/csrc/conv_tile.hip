@@ -48,7 +48,7 @@ __device__ __forceinline__ void tl_split4(const f32x4 v, const float s, u32x2& h
     lo[0] = __builtin_bit_cast(unsigned, l0); lo[1] = __builtin_bit_cast(unsigned, l1);
 }
 
-constexpr int TW = 16, PW = TW + 2;
+constexpr int TW = 16;
 
 struct TileGeom {
     y4::ConvGeom g;
@@ -56,12 +56,17 @@ struct TileGeom {
     int step_b, step_th, step_tw;                         // a block's stride through the tile sequence, as (image, tile row, tile column)
 };
 
-template <int CS, int BN, int TH>
+// S2 = true: the dgrad of a STRIDE-2 conv (32 -> 64 @608 -> 304: the most expensive single layer of the step).  A tile is 16 x 16
+// positions of the dy grid; every filter tap (r, q) feeds exactly one parity class (h & 1, w & 1) of the 32 x 32 output pixels
+// the tile owns -- r = 1 -> even rows from dy row i, r = 0 / 2 -> odd rows from dy rows i + 1 / i -- so the nine taps run out
+// of ONE staged patch of 17 x 17 dy pixels into four accumulator sets, no tap is multiplied by a zero and dy is read once.
+template <int CS, int BN, int TH, bool S2 = false>
 __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom tg) {
     const y4::ConvGeom& g = tg.g;
     constexpr int NW = TH / 2, NT = NW * 64;
     constexpr int CC = CS / 32, KT = 9 * CC;
-    constexpr int PROWS = (TH + 2) * PW, PBUF = PROWS * 128;
+    constexpr int PW = S2 ? TW + 1 : TW + 2, PH = S2 ? TH + 1 : TH + 2, ORG = S2 ? 0 : 1, NCLS = S2 ? 4 : 1;
+    constexpr int PROWS = PH * PW, PBUF = PROWS * 128;
     constexpr int FROW = KT * 128 + (KT % 2 == 0 ? 128 : 0);      // an ODD number of 128-B lines: rows n, n + 1 fall on different bank halves
     constexpr int FBYTES = BN * FROW;
     constexpr int TN = BN / 16;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
             a_off[ir][q] = prow * 128 + ((kq ^ ((prow >> 1) & 7)) << 4);
         }
 
-    accv acc0[2][TN], acc1[2][TN];
+    accv acc0[NCLS][2][TN], acc1[NCLS][2][TN];
     float cs[TN], css[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) { cs[j] = 0.f; css[j] = 0.f; }
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
         const __amdgpu_buffer_rsrc_t rs = y4_make_rsrc(reinterpret_cast<const char*>(g.src) + (unsigned long long)b * img_bytes, (unsigned)img_bytes);
 #pragma unroll
         for (int i = 0; i < PP; ++i) {
-            const int hh = h0 - 1 + s_ph[i], ww = w0 - 1 + s_pw[i];
+            const int hh = h0 - ORG + s_ph[i], ww = w0 - ORG + s_pw[i];
             const bool ok = (unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W;
             const unsigned off = ok ? (unsigned)(hh * W + ww) * pix_bytes + (unsigned)((tid + i * NT) & 7) * 16u : OOB;
             ra[i] = y4_buf_load4(rs, off, (unsigned)cc * 128u);
@@ -174,6 +179,9 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int r = tap / 3, q = tap - 3 * r;
+            // stride 1: patch row offset (r, q), one accumulator set; stride-2 dgrad: tap -> (parity class, dy offset)
+            const int cls = S2 ? ((r == 1 ? 0 : 2) | (q == 1 ? 0 : 1)) : 0;
+            const int dr = S2 ? (r == 0 ? 1 : 0) : r, dq = S2 ? (q == 0 ? 1 : 0) : q;
             const int t = tap * CC + cc;
             f16x8 fb[TN][2];
 #pragma unroll
@@ -183,13 +191,13 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const f16x8 fa0 = *reinterpret_cast<const f16x8*>(pb + a_off[i + r][q]);
-                const f16x8 fa1 = *reinterpret_cast<const f16x8*>(pb + (a_off[i + r][q] ^ 64));
+                const f16x8 fa0 = *reinterpret_cast<const f16x8*>(pb + a_off[i + dr][dq]);
+                const f16x8 fa1 = *reinterpret_cast<const f16x8*>(pb + (a_off[i + dr][dq] ^ 64));
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[j][0], acc1[i][j], 0, 0, 0);
-                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
-                    acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
+                    acc1[cls][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[j][0], acc1[cls][i][j], 0, 0, 0);
+                    acc1[cls][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[cls][i][j], 0, 0, 0);
+                    acc0[cls][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[cls][i][j], 0, 0, 0);
                 }
             }
         }
@@ -203,7 +211,8 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
     for (int j = 0; j < TN; ++j) nok[j] = n0 + j * 16 + fr < g.N;
     const bool allcols = n0 + BN <= g.N;
     const unsigned dpix_bytes = (unsigned)g.ldd * 4u, rpix_bytes = (unsigned)g.ldr * 4u;
-    const unsigned long long dimg_bytes = (unsigned long long)H * W * dpix_bytes, rimg_bytes = (unsigned long long)H * W * rpix_bytes;
+    const int Ho = S2 ? g.Hd : H, Wo = S2 ? g.Wd : W;      // produced map (stride-2 dgrad: twice the dy grid)
+    const unsigned long long dimg_bytes = (unsigned long long)Ho * Wo * dpix_bytes, rimg_bytes = (unsigned long long)Ho * Wo * rpix_bytes;
     auto epilogue_impl = [&](const Tile& tl, auto ALLC, auto RES) {
         constexpr bool allc = decltype(ALLC)::value, with_res = decltype(RES)::value;
         const int b = tl.b, h0 = tl.th * TH, w0 = tl.tw * TW;
@@ -211,22 +220,28 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
         const __amdgpu_buffer_rsrc_t rrs = y4_make_rsrc(with_res ? reinterpret_cast<const char*>(g.res) + (unsigned long long)b * rimg_bytes : nullptr,
                                                         with_res ? (unsigned)rimg_bytes : 0u);
 #pragma unroll
+        for (int cls = 0; cls < NCLS; ++cls)
+#pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int h = h0 + 2 * wave + i;
+            const int hg = h0 + 2 * wave + i;                          // row of the tile grid (stride 1: the output row itself)
+            const int h = S2 ? 2 * hg + (cls >> 1) : hg;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int w = w0 + 4 * kq + e;
-                const bool pok = h < H && w < W;
-                const unsigned pix = (unsigned)(h * W + w);
+                const int wg = w0 + 4 * kq + e;
+                const int w = S2 ? 2 * wg + (cls & 1) : wg;
+                const bool pok = h < Ho && w < Wo;
+                const unsigned pix = (unsigned)(h * Wo + w);
                 const unsigned doff = pok ? pix * dpix_bytes + (unsigned)(n0 + fr) * 4u : OOB;
                 const unsigned roff = pok ? pix * rpix_bytes + (unsigned)(n0 + fr) * 4u : OOB;
                 const float keep = pok ? 1.0f : 0.0f;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                    float v = acc0[cls][i][j][e] * un + acc1[cls][i][j][e] * un1;
                     const bool cok = allc || nok[j];
-                    const float vs = cok ? v * keep : 0.0f;            // statistics: raw result, valid rows / columns only
-                    cs[j] += vs; css[j] += vs * vs;
+                    if constexpr (!S2) {                               // statistics (forward): raw result, valid rows / columns only
+                        const float vs = cok ? v * keep : 0.0f;
+                        cs[j] += vs; css[j] += vs * vs;
+                    }
                     if constexpr (with_res)
                         v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(cok ? roff : OOB), j * 64, 0));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? doff : OOB), j * 64, 0);
@@ -262,11 +277,13 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
         if (more) load_chunk(nx, nx_cc);                   // in flight under the nine taps below
         if (cur_cc == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int c = 0; c < NCLS; ++c)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { acc0[c][i][j][e] = 0.f; acc1[c][i][j][e] = 0.f; }
         }
         compute(buf, cur_cc);
         if (cur_cc == CC - 1) epilogue(cur);
@@ -303,7 +320,7 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
     }
 }
 
-template <int CS, int BN, int TH>
+template <int CS, int BN, int TH, bool S2 = false>
 int launch_tile(const y4::ConvGeom& g, hipStream_t st, int* nparts) {
     TileGeom tg{};
     tg.g = g;
@@ -325,16 +342,16 @@ int launch_tile(const y4::ConvGeom& g, hipStream_t st, int* nparts) {
     }
     if (nparts) *nparts = (int)per;
     constexpr int CC = CS / 32, KT = 9 * CC;
-    constexpr size_t smem = (size_t)BN * (KT * 128 + (KT % 2 == 0 ? 128 : 0)) + 2ull * (TH + 2) * PW * 128;
+    constexpr size_t smem = (size_t)BN * (KT * 128 + (KT % 2 == 0 ? 128 : 0)) + 2ull * (S2 ? (TH + 1) * (TW + 1) : (TH + 2) * (TW + 2)) * 128;
     tg.g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 4ull);
-    auto kern = conv3x3_tile_f16x2<CS, BN, TH>;
+    auto kern = conv3x3_tile_f16x2<CS, BN, TH, S2>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return Y4_ERR_LAUNCH;
         attr_done = true;
     }
-    y4::note_kernel("conv3x3_tile_f16x2<%d, %d, %d>", CS, BN, TH);
+    y4::note_kernel(S2 ? "conv3x3_tile_f16x2<%d, %d, %d, true>" : "conv3x3_tile_f16x2<%d, %d, %d>", CS, BN, TH);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(TH * 32), smem, st, tg);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -361,6 +378,21 @@ int f16x2_tile(const ConvGeom& g, hipStream_t st, int* nparts) {
     // 16 x 16 outputs per tile, 8 waves (two per SIMD): 4 waves on 8 x 16 tiles were 10-25 % slower (one wave per SIMD has
     // nobody to hide its LDS round trips and its epilogue behind)
     return g.Cs == 32 ? launch_tile<32, 64, 16>(g, st, nparts) : launch_tile<64, 32, 16>(g, st, nparts);
+}
+
+// dgrad of a 3x3 / stride-2 / pad-1 conv with 64 (padded) output channels and <= 32 input channels on a large map: the
+// gathered tensor is dy ([B][Hs][Ws][64]), the produced one dx ([B][Hd][Wd][N]); filter planes transposed, NOT mirrored
+bool tile_dgrad_s2_ok(int Cs, int Cs_valid, int N, int k, int stride, int Hs, int Ws) {
+    static const bool off = getenv("Y4_NO_TILE") != nullptr;
+    return !off && k == 3 && stride == 2 && Cs == 64 && Cs_valid == 64 && N >= 1 && N <= 32 && (long long)Hs * Ws >= 100 * 100;
+}
+
+int f16x2_tile_dgrad_s2(const ConvGeom& g, hipStream_t st) {
+    if (!g.wt_planes || g.scale || g.shift || g.dst_amax || g.act != Y4_ACT_LINEAR || g.stats) return Y4_ERR_SHAPE;
+    const unsigned long long pxs = (unsigned long long)g.Hs * g.Ws * 4ull, pxd = (unsigned long long)g.Hd * g.Wd * 4ull;
+    if (pxs * (unsigned long long)g.lds_ >= 0xfffffff0ull || pxd * (unsigned long long)g.ldd >= 0xfffffff0ull ||
+        (g.res && pxd * (unsigned long long)g.ldr >= 0xfffffff0ull)) return Y4_ERR_SHAPE;
+    return launch_tile<64, 32, 16, true>(g, st, nullptr);
 }
 
 }  // namespace y4
