@@ -1180,42 +1180,109 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         }
     };
     unsigned out_max = 0u;
+    // Branch-free epilogue: raw buffer stores / skip-operand loads on a window re-based at the tile's first row whose extent
+    // ends at row M (rows past M fall out of range: the hardware drops them), the lane's row and column in the vector offset,
+    // the accumulator register's row ((e & 3) + 8 (e >> 2)) times the pitch in the SCALAR offset, the column tile as the
+    // immediate: no address arithmetic and no exec-mask branch per element (the per-element `if (valid)` form ran the
+    // launches with a skip operand at 1.9-2.9 TB/s against 4.3-5.3 without one).
+    const unsigned drow_bytes = (unsigned)g.ldd * 4u, rrow_bytes = (unsigned)g.ldr * 4u;
+    // (launches without a skip operand keep the per-element form: they run at 4.1-5.3 TB/s with it, the N = 128 forms have no
+    // registers left for the offset vectors, and the flat form measured 5 % slower on 64 -> 64 @304.  ONE lambda with two bodies: a second, unused closure would still take the
+    // address of the accumulators and push them into scratch)
     auto epilogue = [&](int tile) {
-        const int mbase = tile * TROWS + wave * 32 + 4 * fh;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = j * 32 + fr;
-            const bool nok = n < g.N;
-            // RESB: the skip operand is fetched in batches ahead of the stores (16 cells of a column at NT <= 2, 8 at NT = 4,
-            // where registers are short), as in the gather kernel: a load may not be moved across a store that might alias it
-            constexpr int RB = RESB ? (NT <= 2 ? 16 : 8) : 16;
-#pragma unroll
-            for (int eb = 0; eb < 16; eb += RB) {
-                float rr[RESB ? RB : 1];
-                if constexpr (RESB) {
-#pragma unroll
-                    for (int e = 0; e < RB; ++e) {
-                        const int m = mbase + ((eb + e) & 3) + 8 * ((eb + e) >> 2);
-                        rr[e] = (g.res && nok && m < g.M) ? g.res[(long long)m * g.ldr + n] : 0.f;
-                    }
+        if constexpr (RESB) {
+            const long long row0 = (long long)tile * TROWS;
+            const unsigned long long rows_left = (unsigned long long)(g.M - row0);
+            const unsigned long long dby = rows_left * drow_bytes, rby = rows_left * rrow_bytes;
+            const __amdgpu_buffer_rsrc_t drs = y4_make_rsrc(reinterpret_cast<char*>(g.dst) + row0 * (long long)drow_bytes,
+                                                            (unsigned)(dby < 0xfffffff0ull ? dby : 0xfffffff0ull));
+            const bool has_res = RESB || g.res != nullptr;
+            const __amdgpu_buffer_rsrc_t rrs = y4_make_rsrc(has_res ? reinterpret_cast<const char*>(g.res) + row0 * (long long)rrow_bytes : nullptr,
+                                                            has_res ? (unsigned)(rby < 0xfffffff0ull ? rby : 0xfffffff0ull) : 0u);
+            const int lrow = wave * 32 + 4 * fh;
+            const bool rows_in = row0 + TROWS <= g.M;              // uniform: the whole tile lies inside the tensor
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = j * 32 + fr;
+                const bool nok = n < g.N;
+                // rows 8 g + (e & 3) of the lane's 32-row tile, g = e >> 2: the 8 g part in four vector offsets, the (e & 3) part
+                // in the scalar offset (three scalars instead of sixteen: the kernel is short of SGPRs too)
+                unsigned dvo4[4], rvo4[4];
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    dvo4[q] = nok ? (unsigned)(lrow + 8 * q) * drow_bytes + (unsigned)n * 4u : 0xffffffffu;
+                    rvo4[q] = nok ? (unsigned)(lrow + 8 * q) * rrow_bytes + (unsigned)n * 4u : 0xffffffffu;
                 }
-#pragma unroll
-                for (int ee = 0; ee < RB; ++ee) {
-                    const int e = eb + ee;
-                    const float raw = acc0[j][e] * un + acc1[j][e] * un1;
-                    if constexpr (!PLAIN) { cs[j] += raw; css[j] += raw * raw; }      // rows past M are exact zeros
-                    const int m = mbase + (e & 3) + 8 * (e >> 2);
-                    if (nok && m < g.M) {
+                // the skip operand arrives in batches ahead of the stores: all 16 cells of a column where the launch is known to
+                // have one (RESB), 4 otherwise (registers: the K = 64 / N = 128 form has none to spare)
+                constexpr int RB = RESB ? 16 : 4;
+    #pragma unroll
+                for (int eb = 0; eb < 16; eb += RB) {
+                    float rr[RB];
+                    if (has_res) {
+    #pragma unroll
+                        for (int ee = 0; ee < RB; ++ee) {
+                            const int e = eb + ee;
+                            rr[ee] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(rvo4[e >> 2]), (int)((e & 3) * rrow_bytes), 0));
+                        }
+                    }
+    #pragma unroll
+                    for (int ee = 0; ee < RB; ++ee) {
+                        const int e = eb + ee;
+                        const float raw = acc0[j][e] * un + acc1[j][e] * un1;
+                        if constexpr (!PLAIN) { cs[j] += raw; css[j] += raw * raw; }      // rows past M are exact zeros
                         float v = raw;
                         if constexpr (!PLAIN) {
                             v = raw * sc[j] + sh[j];
                             v = y4_act(v, g.act);
                         }
-                        if constexpr (RESB) v += rr[ee];
-                        else if (g.res) v += g.res[(long long)m * g.ldr + n];
-                        g.dst[(long long)m * g.ldd + n] = v;
-                        const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
-                        if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                        if (has_res) v += rr[ee];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(dvo4[e >> 2]), (int)((e & 3) * drow_bytes), 0);
+                        if (g.dst_amax) {
+                            const bool ok = nok && (rows_in || row0 + lrow + (e & 3) + 8 * (e >> 2) < g.M);
+                            const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
+                            if (ok && vb < 0x7f800000u && vb > out_max) out_max = vb;
+                        }
+                    }
+                }
+            }
+        } else {
+            const int mbase = tile * TROWS + wave * 32 + 4 * fh;
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int n = j * 32 + fr;
+                const bool nok = n < g.N;
+                // RESB: the skip operand is fetched in batches ahead of the stores (16 cells of a column at NT <= 2, 8 at NT = 4,
+                // where registers are short), as in the gather kernel: a load may not be moved across a store that might alias it
+                constexpr int RB = RESB ? (NT <= 2 ? 16 : 8) : 16;
+    #pragma unroll
+                for (int eb = 0; eb < 16; eb += RB) {
+                    float rr[RESB ? RB : 1];
+                    if constexpr (RESB) {
+    #pragma unroll
+                        for (int e = 0; e < RB; ++e) {
+                            const int m = mbase + ((eb + e) & 3) + 8 * ((eb + e) >> 2);
+                            rr[e] = (g.res && nok && m < g.M) ? g.res[(long long)m * g.ldr + n] : 0.f;
+                        }
+                    }
+    #pragma unroll
+                    for (int ee = 0; ee < RB; ++ee) {
+                        const int e = eb + ee;
+                        const float raw = acc0[j][e] * un + acc1[j][e] * un1;
+                        if constexpr (!PLAIN) { cs[j] += raw; css[j] += raw * raw; }      // rows past M are exact zeros
+                        const int m = mbase + (e & 3) + 8 * (e >> 2);
+                        if (nok && m < g.M) {
+                            float v = raw;
+                            if constexpr (!PLAIN) {
+                                v = raw * sc[j] + sh[j];
+                                v = y4_act(v, g.act);
+                            }
+                            if constexpr (RESB) v += rr[ee];
+                            else if (g.res) v += g.res[(long long)m * g.ldr + n];
+                            g.dst[(long long)m * g.ldd + n] = v;
+                            const unsigned vb = __float_as_uint(v) & 0x7fffffffu;
+                            if (vb < 0x7f800000u && vb > out_max) out_max = vb;
+                        }
                     }
                 }
             }
