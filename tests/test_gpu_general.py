@@ -42,6 +42,11 @@ GENERAL = [
     (7, 4, 1, 1, False, 'linear', 9),        # bias, no BN, odd channel counts
     (48, 24, 7, 2, True, 'mish', 17),        # 7x7 stride 2
     (3, 64, 3, 1, True, 'mish', 12),         # 3-channel input with more than 32 filters
+    # few channels on maps >= 100 x 100: the 2-D tile kernel (csrc/conv_tile.hip) inside the module -- forward with BatchNorm
+    # statistics from per-block partial rows, dgrad on the filter planes the forward call prepared, stride-2 dgrad
+    (32, 64, 3, 1, True, 'mish', 112),
+    (64, 64, 3, 1, True, 'leaky_relu', 104),
+    (32, 64, 3, 2, True, 'mish', 208),
 ]
 
 
