@@ -439,6 +439,45 @@ def test_bn_statistics_large_mean(dev):
     close(invstd, 1.0 / torch.sqrt(ref_v + 1e-5), 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 410, 410, 'mish', False), (1, 32, 700, 610, 'leaky_relu', False), (3, 128, 200, 233, 'mish', True),
+                                  (64, 512, 19, 19, 'leaky_relu', True)])
+def test_bn_backward_sweeps_cover_every_row_at_large_sizes(dev, case):
+    """BatchNorm + activation backward (two sweeps + folds) on tensors large enough that a block's share of rows is NOT a
+    multiple of the 4 rows it keeps in flight (the small fixtures never are): dy, dgamma, dbeta against torch fp64, fp32 and
+    plane output.  (A row order that left the last partial group of every block unvisited passed every small test and was
+    caught only by the batch-permutation test of the whole network.)"""
+    from yolov4_amd import ops
+    B, C, H, W, act, planes = case
+    y = recipe.randn((B, C, H, W), 61) * 1.3 + 0.2
+    dz = recipe.randn((B, C, H, W), 62)
+    gamma = recipe.rand((C,), 63) + 0.5
+    beta = recipe.randn((C,), 64) * 0.1
+    y64 = y.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    u = F.batch_norm(y64, None, None, g64, b64, True, 0.1, 1e-5)
+    z = NW.mish(u) if act == 'mish' else F.leaky_relu(u, 0.1)
+    z.backward(dz.double())
+    yd, dzd = cl(y, dev), cl(dz, dev)
+    mean, invstd = ops.bn_stats_raw(yd, None, None, None, 0.1, 1e-5)
+    cell = ops.planes_cell(dev, 8) if planes else None
+    dy, dgamma, dbeta = ops.bn_act_bwd_raw(dzd, yd, mean, invstd, gamma.to(dev), beta.to(dev), act, planes=cell)
+    torch.cuda.synchronize()
+    scale = float(y64.grad.abs().max())
+    assert float((dgamma.double().cpu() - g64.grad).abs().max()) <= 2e-4 * float(g64.grad.abs().max())
+    assert float((dbeta.double().cpu() - b64.grad).abs().max()) <= 2e-4 * float(b64.grad.abs().max())
+    if planes:
+        # [pixel][C / 32][hi 32 halfs | lo 32 halfs], scaled by the power of two of the bound in cell[5]
+        mem = dy.permute(0, 2, 3, 1).contiguous().cpu().numpy()          # NHWC: the bytes as they lie in HBM, 4 per element
+        raw = mem.view(np.float16).reshape(B, H, W, C // 32, 2, 32).astype(np.float64)
+        e8 = (int(cell[5].item()) >> 23) & 0xff
+        s = 2.0 ** (268 - e8 - 127)
+        val = (raw[..., 0, :] + raw[..., 1, :] / 2048.0) / s
+        got = torch.from_numpy(val.reshape(B, H, W, C)).permute(0, 3, 1, 2)
+    else:
+        got = dy.double().cpu()
+    assert float((got - y64.grad).abs().max()) <= 2e-5 * scale
+
+
 # ------------------------------------------------------------------ YOLO head
 @pytest.mark.parametrize('l', [0, 1, 2])
 def test_yololayer_golden(dev, golden, l):

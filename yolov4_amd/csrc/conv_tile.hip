@@ -133,9 +133,13 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
         }
 
     accv acc0[NCLS][2][TN], acc1[NCLS][2][TN];
-    float cs[TN], css[TN];
+    // BatchNorm column sums over ALL tiles of the block (up to ~25 000 pixels per lane and column, from many images): a tile's
+    // eight values per lane are summed first and added to the running sum with a compensated (Kahan) add, so the result does
+    // not depend on which images the block happens to visit (a plain running fp32 sum made the batch-permutation test's
+    // gradients move 4x further than a one-ulp input change)
+    float cs[TN], css[TN], cc[TN], ccs[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { cs[j] = 0.f; css[j] = 0.f; }
+    for (int j = 0; j < TN; ++j) { cs[j] = 0.f; css[j] = 0.f; cc[j] = 0.f; ccs[j] = 0.f; }
 
     const float un = tl_unscale(g.src_amax) * tl_unscale(g.wt_amax);
     const float un1 = un * (1.0f / 2048.0f);
@@ -216,6 +220,9 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
     auto epilogue_impl = [&](const Tile& tl, auto ALLC, auto RES) {
         constexpr bool allc = decltype(ALLC)::value, with_res = decltype(RES)::value;
         const int b = tl.b, h0 = tl.th * TH, w0 = tl.tw * TW;
+        float ts[TN], tss[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { ts[j] = 0.f; tss[j] = 0.f; }
         const __amdgpu_buffer_rsrc_t drs = y4_make_rsrc(reinterpret_cast<char*>(g.dst) + (unsigned long long)b * dimg_bytes, (unsigned)dimg_bytes);
         const __amdgpu_buffer_rsrc_t rrs = y4_make_rsrc(with_res ? reinterpret_cast<const char*>(g.res) + (unsigned long long)b * rimg_bytes : nullptr,
                                                         with_res ? (unsigned)rimg_bytes : 0u);
@@ -240,12 +247,21 @@ __global__ __launch_bounds__(TH * 32, 1) void conv3x3_tile_f16x2(const TileGeom 
                     const bool cok = allc || nok[j];
                     if constexpr (!S2) {                               // statistics (forward): raw result, valid rows / columns only
                         const float vs = cok ? v * keep : 0.0f;
-                        cs[j] += vs; css[j] += vs * vs;
+                        ts[j] += vs; tss[j] += vs * vs;
                     }
                     if constexpr (with_res)
                         v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(cok ? roff : OOB), j * 64, 0));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? doff : OOB), j * 64, 0);
                 }
+            }
+        }
+        if constexpr (!S2) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float y1 = ts[j] - cc[j], t1 = cs[j] + y1;
+                cc[j] = (t1 - cs[j]) - y1; cs[j] = t1;
+                const float y2 = tss[j] - ccs[j], t2 = css[j] + y2;
+                ccs[j] = (t2 - css[j]) - y2; css[j] = t2;
             }
         }
     };
