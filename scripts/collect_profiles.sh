@@ -11,12 +11,19 @@ STEPS="--steps 5 --warmup 2 --no-cpu-baseline"
 KSEL=${Y4_PMC_KERNELS:-}      # e.g. --kernel-include-regex conv
 what=${1:-all}
 
+if [ $what = mfma ]; then
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE $KSEL -d $O/mfma -o m --output-format csv -- python3 $R/bench.py $STEPS > /dev/null 2> $O/mfma.err || exit 1
+  python3 $R/scripts/pmc_mfma_util.py $(find $O/mfma -name "*counter_collection.csv") $O/pmc_mfma_util_per_kernel.json > $O/mfma.txt
+  echo "mfma done"
+fi
 if [ $what = all ] || [ $what = train ] || [ $what = pmc ]; then
   [ $what = pmc ] || timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats -o train --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --conv-table $O/conv_table.txt > $O/train_stats.json 2> $O/train_stats.err || exit 1
   echo "stats done"
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE $KSEL -d $O/fetch -o f --output-format csv -- python3 $R/bench.py $STEPS > /dev/null 2> $O/fetch.err || exit 1
+  sleep 5
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE $KSEL -d $O/write -o w --output-format csv -- python3 $R/bench.py $STEPS > /dev/null 2> $O/write.err || exit 1
   echo "traffic done"
+  sleep 5       # a counter pass started within a second of the previous one has died at tool start-up (twice, always this one)
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE $KSEL -d $O/mfma -o m --output-format csv -- python3 $R/bench.py $STEPS > /dev/null 2> $O/mfma.err || exit 1
   echo "mfma done"
   python3 $R/scripts/pmc_traffic.py $(find $O/fetch -name "*counter_collection.csv") $(find $O/write -name "*counter_collection.csv") $O/pmc_hbm_traffic_per_kernel.json > $O/traffic.txt
