@@ -27,9 +27,10 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     global MODE
     MODE = sys.argv[2] if len(sys.argv) > 2 else 'fwd'
+    only = [int(i) for i in sys.argv[3].split(',')] if len(sys.argv) > 3 else None      # indices into SHAPES
     dev = torch.device('cuda:0')
     out = []
-    for ci, co, k, s, H in SHAPES:
+    for ci, co, k, s, H in ([SHAPES[i] for i in only] if only else SHAPES):
         x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=torch.channels_last)
         w = (torch.randn(co, ci, k, k, device=dev) / np.sqrt(ci * k * k)).contiguous(memory_format=torch.channels_last)
         xa = ops.amax_raw(x)
