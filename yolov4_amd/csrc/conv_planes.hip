@@ -257,50 +257,42 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
     }
 
     // ---- epilogue: c = (acc0 + 2^-11 acc1) / (s_A s_B); 16x16 tile: col = lane & 15, row = 4 (lane >> 4) + e.
-    // Every wave passes its 64 x 64 sub-tile through its own LDS patch ([row][WTN + 4] floats) and writes float4 rows:
-    // a wave instruction stores 4 rows x 256 contiguous bytes.
+    // Branch-free raw buffer stores straight from the accumulators (a wave instruction writes 4 rows x 64 B) on a window
+    // re-based at the tile's first row and ending at row M (rows past M fall out of range and are dropped), the lane's row /
+    // column in the vector offset, the accumulator register e in the scalar offset, the column tile j as the immediate.
+    // 1-4 % faster on every layer shape than passing the tile through per-wave LDS patches to store float4 rows (A/B on
+    // one box), and it leaves the stage memory alone.
     const float un = pl_unscale(g.src_amax) * pl_unscale(g.wt_amax);
     const float un1 = un * (1.0f / 2048.0f);
-    __syncthreads();                                       // every wave has left the last stage
-    constexpr int EP = WTN + 4;
-    constexpr int EPI_BYTES = NWAVE * WTM * EP * 4 + WM * BN * 2 * 4;       // epilogue patches + column sums
-    static_assert(EPI_BYTES <= (NSTAGE * STAGE > 72 * 1024 ? NSTAGE * STAGE : 72 * 1024), "epilogue must fit the dynamic LDS (launcher: max of the two)");
-    float* patch = reinterpret_cast<float*>(smem) + wave * (WTM * EP);
+    {
+        const unsigned drow = (unsigned)g.ldd * 4u, rrow = (unsigned)g.ldr * 4u;
+        const long long row0 = (long long)mt * BM;
+        const unsigned long long left = (unsigned long long)(g.M - row0);
+        const unsigned long long dby = left * drow, rby = left * rrow;
+        const __amdgpu_buffer_rsrc_t drs = y4_make_rsrc(reinterpret_cast<char*>(g.dst) + row0 * (long long)drow, (unsigned)(dby < 0xfffffff0ull ? dby : 0xfffffff0ull));
+        const __amdgpu_buffer_rsrc_t rrs = y4_make_rsrc(g.res ? reinterpret_cast<const char*>(g.res) + row0 * (long long)rrow : nullptr,
+                                                        g.res ? (unsigned)(rby < 0xfffffff0ull ? rby : 0xfffffff0ull) : 0u);
+        const int colb = n0 + wn * WTN + fr;
+        const bool allc = n0 + BN <= g.N;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int i = 0; i < TM; ++i) {
+            const unsigned rl = (unsigned)(wm * WTM + 16 * i + 4 * kq);
+            const unsigned dvo = rl * drow + (unsigned)colb * 4u, rvo = rl * rrow + (unsigned)colb * 4u;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
-                acc0[i][j][e] = v;                         // kept for the column sums
-                patch[(i * 16 + 4 * kq + e) * EP + j * 16 + fr] = v;
-            }
-    // (wave-local: the writes above are ordered before the reads below by the wave's own lgkmcnt wait)
-    constexpr int LPR = WTN / 4, RPI = 64 / LPR;           // lanes per patch row, rows per wave instruction
-    const int c4 = (lane % LPR) * 4;
-    const int nv = n0 + wn * WTN + c4;
-    const bool nok4 = nv < g.N;                            // N % 4 == 0 (host)
-    const long long mrow0 = (long long)mt * BM + wm * WTM;
-#pragma unroll
-    for (int it = 0; it < WTM / RPI; it += 4) {
-        f32x4v rr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long m = mrow0 + (it + u) * RPI + lane / LPR;
-            rr[u] = (g.res && nok4 && m < g.M) ? *reinterpret_cast<const f32x4v*>(g.res + m * g.ldr + nv) : f32x4v{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = (it + u) * RPI + lane / LPR;
-            const long long m = mrow0 + row;
-            f32x4v v = *reinterpret_cast<const f32x4v*>(patch + row * EP + c4);
-            v += rr[u];
-            if (nok4 && m < g.M) *reinterpret_cast<f32x4v*>(g.dst + m * g.ldd + nv) = v;
+                for (int j = 0; j < TN; ++j) {
+                    float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                    acc0[i][j][e] = v;                     // kept for the column sums
+                    const bool cok = allc || colb + 16 * j < g.N;
+                    if (g.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(cok ? rvo + 64u * j : 0xffffffffu), (int)(e * rrow), 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
+                }
         }
     }
     if (g.stats) {                                         // rows past M are exact zeros (their operand rows were zero-filled)
-        float* red = reinterpret_cast<float*>(smem + NWAVE * WTM * EP * 4);       // [WM][BN][2], behind the patches
+        __syncthreads();                                   // every wave has left the last stage
+        float* red = reinterpret_cast<float*>(smem);       // [WM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float cs = 0.f, css = 0.f;
@@ -616,9 +608,7 @@ int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     g.mtiles = (g.M + BM - 1) / BM;
     g.ntiles = (g.N + BN - 1) / BN;
     constexpr int NW = WM * WN;
-    constexpr size_t stages = (NW == 8 ? 3ull : 2ull) * (BM + BN) * PROW;
-    constexpr size_t epi = (size_t)NW * (BM / WM) * (BN / WN + 4) * 4 + (size_t)WM * BN * 2 * 4;
-    constexpr size_t smem = stages > epi ? stages : epi;
+    constexpr size_t smem = (NW == 8 ? 3ull : 2ull) * (BM + BN) * PROW;     // the stages; the epilogue needs WM * BN * 8 B of them
     static_assert(NW == 8 || 2 * smem <= 160 * 1024, "two blocks per CU");
     auto kern = conv_planes_mfma<BM, BN, WM, WN>;
     static bool attr_done = false;
