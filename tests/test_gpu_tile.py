@@ -110,3 +110,25 @@ def test_tile_kernel_stride2_dgrad(dev, case):
     rm, rv = torch.zeros(co, device=dev), torch.ones(co, device=dev)
     ops.conv_fwd_bnstats_raw(x, wd, 3, 2, rm, rv, None, 0.1, 1e-5, dgrad_filter=buf)
     assert torch.equal(ops.conv_dgrad_raw(dyd, wd, (B, ci, H, W), 3, 2, prepared=buf), dx)
+
+
+def test_tile_kernel_on_channel_slices(dev):
+    """pixel pitch > C on all three tensors: the input is a channel slice of a wider buffer, the result goes into a slice of a
+    concat buffer, the skip operand of the dgrad is a slice too (zero-copy concat, as everywhere else in the library)."""
+    from yolov4_amd import ops
+    B, H, W = 2, 104, 112
+    xw = recipe.randn((B, 96, H, W), 71)
+    w = recipe.randn((64, 32, 3, 3), 72, 0.06)
+    xd, wd = cl(xw, dev), cl(w, dev)
+    buf = torch.zeros((B, 192, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+    ops.conv_fwd_raw(xd[:, 32:64], wd, 3, 1, out=buf[:, 64:128])
+    assert ops.last_conv_kernel().startswith('conv3x3_tile_f16x2')
+    ref = F.conv2d(xw[:, 32:64].double(), w.double(), None, 1, 1)
+    assert float((buf[:, 64:128].double().cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float(buf[:, :64].abs().max()) == 0.0 and float(buf[:, 128:].abs().max()) == 0.0
+    dyw = cl(recipe.randn((B, 128, H, W), 73), dev)
+    resw = cl(recipe.randn((B, 64, H, W), 74), dev)
+    dx = ops.conv_dgrad_raw(dyw[:, 64:128], wd, (B, 32, H, W), 3, 1, residual=resw[:, 32:64])
+    assert ops.last_conv_kernel().startswith('conv3x3_tile_f16x2')
+    dref = torch.nn.grad.conv2d_input((B, 32, H, W), w.double(), dyw[:, 64:128].double().cpu(), 1, 1) + resw[:, 32:64].double().cpu()
+    assert float((dx.double().cpu() - dref).abs().max()) <= 1e-5 * float(dref.abs().max())
