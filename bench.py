@@ -39,6 +39,23 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense
 FLOP_PER_IMG_608 = 402.63e9       # fwd + dgrad + wgrad conv flops per image @608
 
 
+class _QuietStdout:
+    """stdout carries exactly ONE line, the JSON result: while the job runs, file descriptor 1 points at stderr, so that whatever
+    a library prints there (RCCL announces its version on stdout when the first communicator is created) cannot get in
+    front of it; `emit` restores the descriptor and prints the line."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        print(line, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -313,6 +330,7 @@ def cpu_baseline(size, batch):
 
 
 def infer_main(args):
+    quiet = _QuietStdout()
     """BASELINE configs[1]: 1xMI355X inference, 608x608 bs=32 (val.py path: eval forward -> postprocess).  One JSON line:
     images/sec of forward + postprocess, and for the HBM-bound head kernels the achieved GB/s against their algorithmic
     bytes (SURVEY 8d: decode reads + writes B*N*85*4 B = 15.47 MB/img; the candidate count reads it once more), measured
@@ -409,13 +427,14 @@ def infer_main(args):
                              'post_scan + post_fill + segment sort + post_nms (data dependent)': {
                                  'ms_per_batch': ms('post_fill_sort_nms'), 'candidates_per_img_target': 500,
                                  'survivors_per_img': surv}}}}
-    print(json.dumps(outj))
+    quiet.emit(json.dumps(outj))
 
 
 def main():
     args = parse()
     if args.infer:
         return infer_main(args)
+    quiet = _QuietStdout()
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -585,7 +604,7 @@ def main():
                 torch.cuda.synchronize(dev)
             out['cpu_baseline']['config0_416_forward_images_per_sec_hip'] = 20.0 / (time.time() - t0)
             model.train()
-        print(json.dumps(out))
+        quiet.emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 
