@@ -79,7 +79,61 @@ def parse():
     ap.add_argument('--infer', action='store_true',
                     help='BASELINE configs[1] instead of the headline: eval forward + YOLO decode + postprocess/NMS at '
                          '--size, --batch 32 by default; reports images/sec and achieved GB/s of the decode / NMS kernels')
+    ap.add_argument('--no-infer-leg', action='store_true',
+                    help='skip the configs[1] inference leg that the default N = 1 run attaches as `inference` after the timed region')
+    ap.add_argument('--stub-step', action='store_true',
+                    help='TEST ONLY (tests/test_host_logic.py): a CPU / gloo stand-in for the step, to exercise the launcher, '
+                         'barrier and max-over-ranks plumbing without a GPU; the line it prints is marked "stub": true and is not a measurement')
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (the form the driver uses for N = 1): start the N ranks
+    as CHILD processes through torch.distributed.run -- this parent has not touched the GPU (importing torch does not), and
+    it never execs -- relay rank 0's one JSON line and exit with the workers' status (reference launch: main_amp.py:94-98,126-131
+    under `python -m torch.distributed.launch`)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, Y4_BENCH_CHILD='1')
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in proc.stdout.decode(errors='replace').splitlines() if l.startswith('{')]
+    if lines:
+        print(lines[-1], flush=True)
+    return proc.returncode if proc.returncode else (0 if lines else 1)
+
+
+def stub_main(args):
+    """--stub-step: the distributed skeleton of main() on CPU tensors over gloo (same rendezvous variables, barrier + timing
+    + MAX over ranks + one line from rank 0), nothing of the hot path."""
+    quiet = _QuietStdout()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world > 1:
+        dist.init_process_group('gloo')
+    w = torch.zeros(1024)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g = torch.full((1024,), float(rank + 1))
+        if world > 1:
+            dist.all_reduce(g)
+            g /= world
+        w += g
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        quiet.emit(json.dumps({'stub': True, 'metric': 'launcher plumbing test, not a measurement', 'value': 0.0, 'n_gpus': world,
+                               'steps': args.steps, 'warmup': args.warmup, 'mean_grad': float(w[0]) / max(args.steps, 1),
+                               'seconds_max_over_ranks': float(t.item())}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 class ConvTimer:
@@ -329,8 +383,7 @@ def cpu_baseline(size, batch):
                       f'torch threads {threads}, host cpus {os.cpu_count()}'}
 
 
-def infer_main(args):
-    quiet = _QuietStdout()
+def infer_leg(args, steps=None, warmup=None):
     """BASELINE configs[1]: 1xMI355X inference, 608x608 bs=32 (val.py path: eval forward -> postprocess).  One JSON line:
     images/sec of forward + postprocess, and for the HBM-bound head kernels the achieved GB/s against their algorithmic
     bytes (SURVEY 8d: decode reads + writes B*N*85*4 B = 15.47 MB/img; the candidate count reads it once more), measured
@@ -345,6 +398,8 @@ def infer_main(args):
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', 0)))
     torch.cuda.set_device(dev)
     B, S = (args.batch if args.batch != 64 else 32), args.size
+    steps = steps if steps is not None else args.steps
+    warmup = warmup if warmup is not None else args.warmup
     m = YOLOv4(recipe.MODEL_CFG, device=dev)
     sd = m.state_dict()
     recipe.fill_state_dict_(sd, 1234)
@@ -372,7 +427,7 @@ def infer_main(args):
     bracket(L, 'y4_post_count_f32', 'post_count')
     bracket(L, 'y4_post_nms_f32', 'post_fill_sort_nms')
     with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
+        for _ in range(max(warmup, 1)):
             out = m(x)
         sc = (out[..., 4:5] * out[..., 5:]).flatten()
         # confidence threshold giving ~500 candidates per image (survivors 1e2..1e3 per image)
@@ -382,7 +437,7 @@ def infer_main(args):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tf = tp = 0.0
-        for _ in range(args.steps):
+        for _ in range(steps):
             a = time.perf_counter()
             out = m(x)
             torch.cuda.synchronize()
@@ -393,7 +448,7 @@ def infer_main(args):
             tp += time.perf_counter() - b_
         dt = time.perf_counter() - t0
     N = out.shape[1]
-    ms = lambda key: sum(e0.elapsed_time(e1) for e0, e1 in rec[key]) / args.steps
+    ms = lambda key: sum(e0.elapsed_time(e1) for e0, e1 in rec[key]) / steps
     dec_bytes = 2.0 * B * N * 85 * 4
     cnt_bytes = 1.0 * B * N * 85 * 4 + B * N * 4 * 4        # reads every score once, rewrites the 4 box columns (xyxy)
     surv = sum(0 if d is None else len(d) for d in det) / B
@@ -405,15 +460,15 @@ def infer_main(args):
         by = 2.0 * B * 3 * F_ * F_ * 85 * 4
         per_layer[f'F={F_}'] = {'ms': t_ms, 'GB/s': by / (t_ms * 1e-3) / 1e9, 'algorithmic_bytes': by}
     outj = {'metric': f'images/sec inference @{S}x{S} bs={B} (eval forward + YOLO decode + postprocess / per-class NMS)',
-            'value': B * args.steps / dt, 'unit': 'images/sec', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'value': B * steps / dt, 'unit': 'images/sec', 'n_gpus': 1, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'configs[1]: 1xMI355X inference, {S}x{S} bs={B}, BN folded into the conv epilogues, random '
                                    f'weights with BatchNorm statistics calibrated at {S}', 'conv_arithmetic': MODES[args.conv_mode]['text'],
                        'conf_thre': thr, 'nms_thre': 0.4, 'survivors_per_img': surv, 'boxes_per_img': N,
-                       'forward_ms': tf / args.steps * 1e3, 'postprocess_ms': tp / args.steps * 1e3,
-                       'forward_images_per_sec': B * args.steps / tf,
-                       'forward_conv_tflops': B * args.steps / tf * 134.422e9 * (S / 608.0) ** 2 / 1e12},
+                       'forward_ms': tf / steps * 1e3, 'postprocess_ms': tp / steps * 1e3,
+                       'forward_images_per_sec': B * steps / tf,
+                       'forward_conv_tflops': B * steps / tf * 134.422e9 * (S / 608.0) ** 2 / 1e12},
             'roofline': {'bound': 'hbm', 'kernel': 'yolo_decode_tiled_kernel<true, 32 | 16> (3 launches per batch)',
                          'achieved': dec_bytes / (ms('decode') * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': dec_bytes / (ms('decode') * 1e-3) / 1e9 / 8000.0, 'traffic': None,
@@ -427,13 +482,18 @@ def infer_main(args):
                              'post_scan + post_fill + segment sort + post_nms (data dependent)': {
                                  'ms_per_batch': ms('post_fill_sort_nms'), 'candidates_per_img_target': 500,
                                  'survivors_per_img': surv}}}}
-    quiet.emit(json.dumps(outj))
+    return outj
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+    if args.stub_step:
+        return stub_main(args)
     if args.infer:
-        return infer_main(args)
+        quiet = _QuietStdout()
+        return quiet.emit(json.dumps(infer_leg(args)))
     quiet = _QuietStdout()
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -604,6 +664,18 @@ def main():
                 torch.cuda.synchronize(dev)
             out['cpu_baseline']['config0_416_forward_images_per_sec_hip'] = 20.0 / (time.time() - t0)
             model.train()
+        if world == 1 and not args.no_infer_leg and args.conv_mode == 'f16x2' and args.batch == 64:
+            # BASELINE configs[1] on the same clock, AFTER the headline's timed region (it shares nothing with it: its own model
+            # in eval mode, batch 32): eval forward + decode + postprocess for a few batches -> `inference`
+            del loss
+            ddp.zero_grad()
+            torch.cuda.empty_cache()
+            leg = infer_leg(args, steps=6, warmup=2)
+            out['inference'] = {'metric': leg['metric'], 'value': leg['value'], 'unit': leg['unit'], 'ms_per_step': leg['ms_per_step'],
+                                'steps': leg['steps'], 'warmup': leg['warmup'],
+                                'forward_ms': leg['config']['forward_ms'], 'postprocess_ms': leg['config']['postprocess_ms'],
+                                'survivors_per_img': leg['config']['survivors_per_img'], 'workload': leg['config']['workload'],
+                                'roofline': leg['roofline']}
         quiet.emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

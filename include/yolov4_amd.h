@@ -94,8 +94,8 @@ int y4_conv2d_fwd_f32(const float* x, int ldx, const float* w, float* y, int ldy
  * (word 0: bit pattern of max|w|; word 1: scratch of the conv call; words 2-5: 64-bit fingerprint, valid flag, ticket), 4 KiB of
  * fingerprint partials, then the fp16 hi/lo planes interleaved per 32-deep K tile; y4_conv2d_prepared_bytes(Cout, K) bytes in
  * all, whose first 64 bytes the caller ZEROES once after allocating.  y4_conv2d_prepare_filter_f32 is a REFRESH: it reads the
- * filter once (maximum + exact positional checksum of its bit patterns) and re-splits it only if the bits differ from what
- * the buffer holds -- decided on the device, so a stale buffer cannot be used whatever wrote the weights (optimizer kernels,
+ * filter once (maximum + a 64-bit positional hash of its bit patterns; collision probability 2^-64) and re-splits it only if
+ * either differs from what the buffer holds -- decided on the device, so a stale buffer cannot be used whatever wrote the weights (optimizer kernels,
  * `.data` writes, load_state_dict).  Call it before every y4_conv2d_fwd_prepared_f32: same arithmetic and results as
  * y4_conv2d_fwd_f32 at one read pass instead of two reads + one write pass over the filter.  (The reference has no
  * counterpart: nn.Conv2d re-reads its weight every call.) */

@@ -78,6 +78,51 @@ def test_convbnact_any_shape_train_forward_backward(dev, cfg):
         assert float((m.conv.bias.grad.cpu().double() - ref[0].bias.grad).abs().max()) <= tol(ref[0].bias.grad)
 
 
+EVAL_GENERAL = GENERAL[:6] + [
+    # general layers whose result feeds a conv of the implicit-GEMM family (Cout a multiple of 32)
+    (5, 32, 3, 1, True, 'mish', 11),
+    (48, 64, 7, 2, True, 'leaky_relu', 17),
+    (7, 32, 1, 1, False, 'linear', 9),
+]
+
+
+@pytest.mark.parametrize('cache', [True, False])
+@pytest.mark.parametrize('cfg', EVAL_GENERAL)
+def test_convbnact_any_shape_eval_no_grad_then_fast_conv(dev, cfg, cache, monkeypatch):
+    """model.eval() + torch.no_grad() (the val.py path) over the general shapes, with and without the per-parameter
+    inference caches (the prepared-filter cache used to be asked for K not a multiple of 32, and the general
+    kernel's result used to travel with a zeroed maximum cell).  Where the channel count allows, a 3x3 layer of the f16x2
+    family consumes the result, whose magnitude (>> 65504) overflows fp16 unless the consumer scales by the true maximum."""
+    from yolov4_amd.darknet.darknet import ConvBNAct
+    cin, cout, k, s, bn, act, H = cfg
+    if not cache:
+        monkeypatch.setenv('Y4_NO_INFER_CACHE', '1')
+    torch.manual_seed(37)
+    m = ConvBNAct(cin, cout, k, s, bias=not bn, bn=bn, act=act).to(dev)
+    if bn:
+        nn.init.uniform_(m.norm.weight, 2e5, 4e5)            # activations of order 1e5 .. 1e6
+        nn.init.normal_(m.norm.bias, 0, 0.2)
+        m.norm.running_mean.normal_(0, 0.3)
+        m.norm.running_var.uniform_(0.5, 2.0)
+    else:
+        m.conv.weight.data.mul_(3e5)
+    mods, refs = [m], [_ref_module(m, act)]
+    if cout % 32 == 0:
+        m2 = ConvBNAct(cout, 64, 3, 1, act='leaky_relu').to(dev)
+        m2.norm.running_mean.normal_(0, 0.3)
+        m2.norm.running_var.uniform_(0.5, 2.0)
+        mods.append(m2)
+        refs.append(_ref_module(m2, 'leaky_relu'))
+    x = torch.randn(2, cin, H, H)
+    z, zr = x.to(dev), x.double()
+    with torch.no_grad():
+        for mm, rr in zip(mods, refs):
+            z, zr = mm.eval()(z), rr.eval()(zr)
+    z = z.cpu().double()
+    assert bool(torch.isfinite(z).all())
+    assert float((z - zr).abs().max()) <= 2e-4 * float(zr.abs().max())
+
+
 @pytest.mark.parametrize('cfg', [(64, 128, 3, 1, 'mish', 19), (32, 64, 1, 1, 'leaky_relu', 20), (3, 32, 3, 1, 'mish', 24)])
 def test_backward_through_eval_mode_batchnorm_and_input_gradient(dev, cfg):
     """Frozen running statistics under autograd (eval mode, requires_grad inputs): dy = gamma invstd g without the batch

@@ -15,6 +15,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static inline hipStream_t y4_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: one flag word per launcher
+// instantiation, bit d = "set on device d" (devices >= 64: set on every launch).  Two threads racing through their first
+// launch both set the attribute, which is idempotent.
+#include <atomic>
+struct Y4DynLds {
+    std::atomic<unsigned long long> done{0ull};
+    bool ensure(const void* kernel, size_t bytes) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return false;
+        if (d >= 0 && d < 64 && ((done.load(std::memory_order_acquire) >> d) & 1ull)) return true;
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+        if (d >= 0 && d < 64) done.fetch_or(1ull << d, std::memory_order_release);
+        return true;
+    }
+};
+
 // darknet/darknet.py:14-20: x * tanh(softplus(x)).  With n = e^x:
 // tanh(log(1+n)) = ((1+n)^2-1)/((1+n)^2+1) = n(n+2)/(n(n+2)+2); softplus threshold 20 of
 // torch (returns x above it) coincides with the ratio being exactly 1.0f there.

@@ -1077,12 +1077,8 @@ int launch_halo_f16x2(const ConvGeom& g0, hipStream_t st, int* nparts) {
     if (nparts) *nparts = g.mtiles;
     const size_t smem = 2ull * HALO_ROWS * ROWB + 2ull * 2 * BN * ROWB;
     auto kern = conv3x3_halo_f16x2<BN, TR, MS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     y4::note_kernel("conv3x3_halo_f16x2<%d, %s, %d>", BN, TR ? "true" : "false", MS);
     hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(256), smem, st, g, tiles_per_img);
     Y4_CHECK_LAUNCH();
@@ -1366,12 +1362,8 @@ int launch_stream1x1_f16x2_impl(const ConvGeom& g0, hipStream_t st, int* nparts)
     const size_t red = (size_t)NW * NT * 32 * 2 * sizeof(float);
     if (smem < red) smem = red;
     auto kern = conv1x1_stream_f16x2<KS, NT, NW, RESB, PLAIN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     const int resident = NW == 8 ? 256 : 512;             // blocks per CU: 1 (8 waves) or 2
     const int grid = g.mtiles < resident ? g.mtiles : resident;
     if (nparts) *nparts = grid;
@@ -1577,8 +1569,9 @@ __global__ __launch_bounds__(256) void f16x2_transpose_split_filter_folded_kerne
     }
 }
 
-// ---- inference: a prepared filter buffer is refreshed only when the filter's BITS changed (exact 64-bit positional
-// checksum, order independent), decided on the device: no host sync, no version counters to trust.  ONE launch per call:
+// ---- inference: a prepared filter buffer is refreshed only when the filter's BITS changed -- judged by a 64-bit positional
+// HASH of the bit patterns (order independent to compute; two different filters collide with probability 2^-64, it is not a
+// proof of equality) together with the exact maximum -- decided on the device: no host sync, no version counters to trust.  ONE launch per call:
 // every block fingerprints its slice and takes a ticket; the last one folds the partials and compares with the header --
 // unchanged (every call but the first after a weight update): done; changed: that block re-splits the whole filter (rare,
 // so its serial cost -- at most 0.4 ms for the largest filter -- does not matter).
@@ -1709,12 +1702,8 @@ int launch_gather_f16x2(const ConvGeom& g0, hipStream_t st) {
     }
     size_t smem = (size_t)gather_rowm_off<BM, BN, WM, WN, MS>() + BM * sizeof(int);
     auto kern = conv_gather_f16x2<BM, BN, WM, WN, TR, MS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     int grid = g.mtiles * g.ntiles;
     if (TR && g.stride == 2) {
         int sl = 0;
@@ -1753,12 +1742,8 @@ template <int TN_, int TJ_, int MS>
 int launch_wgrad_f16x2(const WgradGeom& g, hipStream_t st) {
     const size_t smem = 2ull * 2 * (TN_ + TJ_) * ROWB;
     auto kern = conv_wgrad_f16x2<TN_, TJ_, MS>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     y4::note_kernel("conv_wgrad_f16x2<%d, %d, %d>", TN_, TJ_, MS);
     hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();

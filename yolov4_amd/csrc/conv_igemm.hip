@@ -695,12 +695,8 @@ int launch_gather(const ConvGeom& g0, hipStream_t st) {
     void (*kern)(const ConvGeom);
     if constexpr (SPLIT) kern = conv_gather_bf16x3<BM, BN, WM, WN, TR, (NP > 0 ? NP : 3)>;
     else kern = conv_gather_mfma_f32<BM, BN, WM, WN, TR, BKT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     int grid = g.mtiles * g.ntiles;
     if (TR && g.stride == 2) {
         int sl = 0;
@@ -890,12 +886,8 @@ int launch_stream1x1(const ConvGeom& g0, hipStream_t st, int* nparts) {
     g.src_total_bytes = (unsigned long long)g.M * (unsigned long long)g.lds_ * 4ull;
     const size_t smem = (size_t)3 * NT * 32 * (KS * 32 + 16);
     auto kern = conv1x1_stream_bf16x3<KS, NT, NW>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     const int resident = smem > 80 * 1024 ? 256 : 512;    // blocks per CU by LDS: 1 (K = N = 128) or 2
     const int grid = g.mtiles < resident ? g.mtiles : resident;
     if (nparts) *nparts = grid;
@@ -1412,12 +1404,8 @@ int launch_wgrad(const WgradGeom& g, hipStream_t st) {
     void (*kern)(const WgradGeom);
     if constexpr (SPLIT) kern = conv_wgrad_bf16x3<TN_, TJ_, (NP > 0 ? NP : 3)>;
     else kern = conv_wgrad_mfma_f32<TN_, TJ_>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess) return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(256), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;

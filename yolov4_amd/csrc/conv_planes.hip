@@ -611,12 +611,8 @@ int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     constexpr size_t smem = (NW == 8 ? 3ull : 2ull) * (BM + BN) * PROW;     // the stages; the epilogue needs WM * BN * 8 B of them
     static_assert(NW == 8 || 2 * smem <= 160 * 1024, "two blocks per CU");
     auto kern = conv_planes_mfma<BM, BN, WM, WN>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d>", BM, BN, WM, WN);
     hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
@@ -707,12 +703,8 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     }
     constexpr size_t smem = 3ull * (128 / 32 + 256 / 32) * 32 * PROW;
     auto kern = wgrad_planes_mfma<128, 256>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     y4::note_kernel("wgrad_planes_mfma<128, 256>");
     hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(512), smem, st, g);
     Y4_CHECK_LAUNCH();

@@ -361,12 +361,8 @@ int launch_tile(const y4::ConvGeom& g, hipStream_t st, int* nparts) {
     constexpr size_t smem = (size_t)BN * (KT * 128 + (KT % 2 == 0 ? 128 : 0)) + 2ull * (S2 ? (TH + 1) * (TW + 1) : (TH + 2) * (TW + 2)) * 128;
     tg.g.wt_bytes = (unsigned)((unsigned long long)g.N * g.K * 4ull);
     auto kern = conv3x3_tile_f16x2<CS, BN, TH, S2>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return Y4_ERR_LAUNCH;
-        attr_done = true;
-    }
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
     y4::note_kernel(S2 ? "conv3x3_tile_f16x2<%d, %d, %d, true>" : "conv3x3_tile_f16x2<%d, %d, %d>", CS, BN, TH);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(TH * 32), smem, st, tg);
     Y4_CHECK_LAUNCH();

@@ -60,6 +60,7 @@ class ConvBNAct(nn.Module):
         (tensor attribute y4_twin, handed on by ops.fork).  The reference has none of these arguments."""
         n = self.norm
         io = {}
+        out_planes = soft(out_planes, self)
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
                'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes,
@@ -87,10 +88,31 @@ class ConvBNAct(nn.Module):
         cfg['weight_param'] = self.conv.weight       # its gradient may be produced on the side stream (ops._wgrad_to_param)
         z = ops.ConvBNActFn.apply(x, w, self.conv.bias, gamma, beta, residual, cfg)
         if io.get('z_planes'):
-            z.y4_planes = True                       # (tags do not survive autograd's output wrapping: set on the result)
+            z = ops.as_planes(z)                     # (tags do not survive autograd's output wrapping: set on the result)
         if io.get('z_twin') is not None:
             z.y4_twin = io['z_twin']
         return ops.tag_amax(z, io.get('z_amax'))
+
+
+def observed(*mods):
+    """True if somebody may look at what one of these modules receives or returns: a forward / backward (pre-)hook on it,
+    or a global module hook (torch.nn.modules.module.register_module_forward_hook ...).  Observed modules never see or
+    return a pre-split tensor: producers write fp32 with a pre-split twin ('both') instead, hooked containers that the fast
+    path would step over (nn.Sequential pairs and chains) are CALLED, so that their hooks fire as in the reference."""
+    g = torch.nn.modules.module
+    if (g._global_forward_hooks or g._global_forward_pre_hooks or g._global_backward_hooks or g._global_backward_pre_hooks
+            or getattr(g, '_global_forward_hooks_always_called', None)):
+        return True
+    for m in mods:
+        if m is not None and (m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks):
+            return True
+    return False
+
+
+def soft(want, *mods):
+    """out_planes request `want`, downgraded from planes-only (True) to fp32 + twin ('both') when one of `mods` -- the
+    modules through whose interface the tensor will pass -- is observed."""
+    return 'both' if (want is True and observed(*mods)) else want
 
 
 def takes_planes(m):
@@ -109,10 +131,12 @@ def chain(seq, x, last=False):
     """nn.Sequential of ConvBNAct layers, each feeding only the next: intermediates leave pre-split where the consumer
     can take them (same results as seq(x); the reference calls the Sequential).  last: out_planes of the final layer
     (True: its sole consumer takes planes; 'both': one of several does)."""
+    if observed(seq):
+        return seq(x)                                # hooks on the Sequential itself: the plain call (all-fp32 intermediates)
     mods = list(seq)
     for i, m in enumerate(mods):
         nxt = mods[i + 1] if i + 1 < len(mods) else None
-        want = takes_planes(nxt) if nxt is not None else last
+        want = soft(takes_planes(nxt), nxt) if nxt is not None else last
         x = m(x, out_planes=want) if isinstance(m, ConvBNAct) else m(x)
     return x
 
@@ -122,8 +146,11 @@ def res_unit(pair, x, out_planes=False):
     arriving over the skip is parked by the 3x3 and added in the 1x1's dgrad epilogue, so neither direction spends a
     separate elementwise pass.  out_planes: as ConvBNAct.forward, for the unit's result."""
     xa, xb = ops.fork(x)
+    if observed(pair):
+        return ops.AddFn.apply(xb, pair(xa))         # hooks on the pair: the reference's x + module(x), unfused
     box = {} if (torch.is_grad_enabled() and xa.requires_grad and pair[0].training) else None
-    return pair[1](pair[0](xa, dres_take=box, out_planes=takes_planes(pair[1])), residual=xb, dres_put=box, out_planes=out_planes)
+    return pair[1](pair[0](xa, dres_take=box, out_planes=soft(takes_planes(pair[1]), pair[1])), residual=xb, dres_put=box,
+                   out_planes=out_planes)
 
 
 # A residual unit's result feeds the next unit's 1x1 conv AND its skip: fp32 for the skip plus a pre-split twin for the conv
@@ -148,7 +175,7 @@ class ResBlock(nn.Module):
                 if i + 1 < n:
                     want = 'both' if (_TWIN_RES and takes_planes(self.module_list[i + 1][0])) else False
                 else:
-                    want = out_planes
+                    want = soft(out_planes, self)
                 x = res_unit(pair, x, out_planes=want)
             else:
                 x = pair[1](pair[0](x))
@@ -192,13 +219,17 @@ class CSPDownSample(nn.Module):
 
     def forward(self, x):
         # both consumers of the stride-2 conv's result are 1x1 convs: where both take planes the result leaves pre-split only
-        both = _TWIN_RES and takes_planes(self.part1) and takes_planes(self.part2[0])
+        both = soft(bool(_TWIN_RES and takes_planes(self.part1) and takes_planes(self.part2[0])), self.part1, self.part2, self.part2[0])
         xa, xb = ops.fork(self.base(x, out_planes=both))
         cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels])
         x1 = self.part1(xa, out=cb.slot(1))
+        if observed(self.part2):
+            x2 = self.part2(xb)                      # hooks on the Sequential: the plain call; cat copies its result in
+            return self.transition(ops.cat([x2, x1], into=cb))
         blk = self.part2[1]
         # part2[0]'s result feeds the first unit's 1x1 conv and its skip; the block's result feeds part2[2] alone
         first = 'both' if (blk.shortcut and blk.first_takes_planes()) else False
-        x2 = blk(self.part2[0](xb, out_planes=first), out_planes=blk.shortcut and _TWIN_RES and takes_planes(self.part2[2]))
+        last = soft(bool(blk.shortcut and _TWIN_RES and takes_planes(self.part2[2])), blk, self.part2[2])
+        x2 = blk(self.part2[0](xb, out_planes=first), out_planes=last)
         x2 = self.part2[2](x2, out=cb.slot(0))
         return self.transition(ops.cat([x2, x1], into=cb))

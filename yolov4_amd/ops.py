@@ -327,6 +327,49 @@ class Planes:
         self.buf, self.shape, self.amax = buf, tuple(shape), amax
 
 
+class PlanesTensor(torch.Tensor):
+    """What a pre-split activation looks like from Python: float32-TYPED (autograd only differentiates floating outputs, and
+    the bytes travel through autograd.Function like any activation) but its 4 bytes per element are two fp16 pieces, not a
+    float.  Only ConvBNAct consumes it (ops.planes_of); everything an observer would do with an activation -- .cpu(),
+    .numpy(), arithmetic, indexing, printing values, torch.save -- fails loudly instead of yielding garbage.  A module with
+    forward hooks never hands one out (darknet.observed): its result is then fp32 with the pre-split copy as `y4_twin`."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def _refuse(self, *a, **kw):
+        raise Y4Error('this tensor holds a PRE-SPLIT activation (two fp16 pieces per element, csrc/conv_planes.hip), not '
+                      'float32 values: only ConvBNAct can consume it.  Register the forward hook before the forward pass '
+                      '(hooked modules return fp32), or run with Y4_PLANES=0 to keep every intermediate tensor fp32.')
+
+    cpu = to = numpy = tolist = item = float = double = half = bfloat16 = int = long = clone = _refuse
+    sum = mean = abs = max = min = amax = amin = norm = std = var = exp = log = sigmoid = tanh = relu = _refuse
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __neg__ = __pow__ = _refuse
+    __iadd__ = __isub__ = __imul__ = __itruediv__ = __matmul__ = __getitem__ = __setitem__ = _refuse
+    __lt__ = __le__ = __gt__ = __ge__ = __float__ = __int__ = __bool__ = __array__ = __dlpack__ = _refuse
+    __reduce_ex__ = __reduce__ = __deepcopy__ = _refuse                      # torch.save, pickle, copy.deepcopy
+
+    def __repr__(self, *a, **kw):
+        return (f'PlanesTensor(shape={tuple(self.shape)}, device={self.device}: pre-split fp16 pairs, NOT float32 values; '
+                'see yolov4_amd.ops.PlanesTensor)')
+
+    __str__ = __repr__
+
+    def __format__(self, spec):
+        return self.__repr__()
+
+    def detach(self):
+        return as_planes(torch.Tensor.detach(self), getattr(self, 'y4_amax', None))
+
+
+def as_planes(t, cell=None):
+    """Mark tensor t (same memory, still attached to the autograd graph) as a pre-split activation."""
+    if type(t) is not PlanesTensor:
+        t = t.as_subclass(PlanesTensor)
+    t.y4_planes = True
+    if cell is not None:
+        t.y4_amax = cell
+    return t
+
+
 def planes_split_raw(x, amax=None):
     """fp32 NHWC tensor -> Planes (one read + one write pass; tensors whose producer does not emit planes itself)."""
     L = lib()
@@ -561,11 +604,11 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
             mode = 2
         check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), mode, _ptr(res_cell),
                                   _ptr(zp) if both else None, _stream()), 'bn_act_fwd(planes)')
-        zp.y4_planes = True
-        tag_amax(zp, cell)
+        zp = as_planes(zp, cell)
         if both:
             z.y4_twin = zp                           # fp32 for everybody else, planes for the conv that can take them
-        return tag_amax(z, cell[0:1])
+            return tag_amax(z, cell[0:1])
+        return as_planes(zp, cell[0:1])
     z = out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)
     check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act],
                               _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), 0, None, None, _stream()),
@@ -778,12 +821,16 @@ class ConvBNActFn(torch.autograd.Function):
         elif bn:
             # no autograd in flight (val.py / detect.py): the filter planes and the BN fold are per-parameter-version caches
             frozen = not cfg.get('grad', True) and os.environ.get('Y4_NO_INFER_CACHE') != '1'
-            wprep = prepared_filter(cfg['weight_param']) if (frozen and f16 and cfg.get('weight_param') is not None) else None
+            # shapes outside the implicit-GEMM kernels run on the direct kernels (conv_generic.hip): those take fp32 filters
+            # as they are (no prepared planes: K need not be a multiple of 32) and leave no maximum behind, so their result
+            # stays untagged and the consumer measures it itself
+            fast = f16 and fast_conv_shape(x.shape[1], k, s)
+            wprep = prepared_filter(cfg['weight_param']) if (frozen and fast and cfg.get('weight_param') is not None) else None
             scale, shift = bn_fold_raw(gamma, beta, cfg['running_mean'], cfg['running_var'], cfg['eps'])
             o = dest
             Ho, Wo = conv_out_hw(x.shape[2], x.shape[3], k, s)
             o = o if _slot_ok(o, (x.shape[0], weight.shape[0], Ho, Wo)) else None
-            if f16:
+            if fast:
                 z_amax = live(cfg.get('out_amax')) if o is not None else None
                 if z_amax is None:                   # (never truth-test a device tensor: that is a host sync)
                     z_amax = new_amax(x.device)
@@ -791,7 +838,8 @@ class ConvBNActFn(torch.autograd.Function):
                              w_prepared=wprep)
             ctx.mode = 'bn_eval'
         else:
-            wprep = prepared_filter(cfg['weight_param']) if (not cfg.get('grad', True) and f16 and os.environ.get('Y4_NO_INFER_CACHE') != '1'
+            wprep = prepared_filter(cfg['weight_param']) if (not cfg.get('grad', True) and f16 and fast_conv_shape(x.shape[1], k, s)
+                                                              and os.environ.get('Y4_NO_INFER_CACHE') != '1'
                                                               and cfg.get('weight_param') is not None) else None
             z = conv_fwd_raw(x, weight, k, s, None, bias, act, residual, out_pad=32, x_amax=x_amax, w_prepared=wprep)
             if act != 'linear':
@@ -918,9 +966,22 @@ def fork(x):
     if twin is not None:
         a.y4_twin = b.y4_twin = twin
     if getattr(x, 'y4_planes', False):               # a pre-split tensor read by two plane-taking convs (CSP split convs)
-        a.y4_planes = b.y4_planes = True
-        return tag_amax(a, x.y4_amax), tag_amax(b, x.y4_amax)
+        return as_planes(a, x.y4_amax), as_planes(b, x.y4_amax)
     return tag_amax(a, cell), tag_amax(b, cell)
+
+
+class AddFn(torch.autograd.Function):
+    """a + b as a library kernel (the unfused ResBlock skip, used only where a hooked container forces the plain call path)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a, 'add input')
+        _require_gpu(b, 'add input')
+        return add_raw(a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
 
 
 class CatBuffer:

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from ... import ops
-from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain, takes_planes
+from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain, observed, soft, takes_planes
 from .yololayer import YOLOLayer
 
 L = 'leaky_relu'
@@ -58,7 +58,7 @@ class SPPBlock(nn.Module):
 
     def forward(self, x, out_planes=False):
         """out_planes: the sole consumer (fpn.module1[0]) takes a pre-split input; the reference has no such argument."""
-        return self.conv2(ops.spp_pool_cat(chain(self.conv1, x)), out_planes=out_planes)
+        return self.conv2(ops.spp_pool_cat(chain(self.conv1, x)), out_planes=soft(out_planes, self))
 
 
 class Upsample(nn.Module):
@@ -141,7 +141,7 @@ class PANBlock(nn.Module):
         cb = ops.cat_buffer(f3, [512, f3.shape[1]])
         p3 = self.conv7(p2a, out=cb.slot(0))
         assert p3.shape[2:] == f3.shape[2:]
-        p3 = chain(self.module2, ops.cat([p3, f3], into=cb), last=bool(head_planes[1]))
+        p3 = chain(self.module2, ops.cat([p3, f3], into=cb), last=soft(head_planes[1], self))
         return p1, p2b, p3
 
 
@@ -155,7 +155,7 @@ class Neck(nn.Module):
 
     def forward(self, x3, x4, x5, head_planes=(False, False, False)):
         """head_planes: which of the three head 3x3 convs take pre-split inputs (YOLOv4.forward asks them)."""
-        x5 = self.spp(x5, out_planes=takes_planes(self.fpn.module1[0]))
+        x5 = self.spp(x5, out_planes=soft(takes_planes(self.fpn.module1[0]), self.fpn, self.fpn.module1, self.fpn.module1[0]))
         return self.pan(*self.fpn(x3, x4, x5, head_planes=head_planes[0]), head_planes=head_planes[1:])
 
 
@@ -179,6 +179,8 @@ class Head(nn.Module):
         return [h[1](h[0](p)) for h, p in ((self.yolo1, p1), (self.yolo2, p2), (self.yolo3, p3))]
 
     def forward(self, p1, p2, p3):
+        if observed(self.yolo1, self.yolo2, self.yolo3):
+            return tuple(h(p) for h, p in ((self.yolo1, p1), (self.yolo2, p2), (self.yolo3, p3)))    # hooks on a Sequential: call it
         return tuple(h[2](lg) for h, lg in zip((self.yolo1, self.yolo2, self.yolo3), self.logits(p1, p2, p3)))
 
 
@@ -211,10 +213,14 @@ class YOLOv4(nn.Module):
     def forward(self, x):
         if x.dtype != torch.float32:
             x = x.float()              # Transform hands float64 images; apex O0 casts them
-        hp = tuple(takes_planes(h[0]) for h in (self.head.yolo1, self.head.yolo2, self.head.yolo3))
+        # (True: the head conv may be the SOLE reader of a pre-split tensor; 'both' where somebody may be looking on the way)
+        hp = tuple(soft(takes_planes(h[0]), self.neck, self.neck.pan, self.head, h, h[0])
+                   for h in (self.head.yolo1, self.head.yolo2, self.head.yolo3))
         p1, p2, p3 = self.neck(*self.backbone(x), head_planes=hp)
         if self.training:
             return list(self.head(p1, p2, p3))
+        if observed(self.head, self.head.yolo1, self.head.yolo2, self.head.yolo3):
+            return torch.cat(list(self.head(p1, p2, p3)), dim=1)     # hooked head: the reference's call sequence (yolov4.py:316-324)
         # eval: the three decodes write into one [B, N, 5+C] buffer (the cat of yolov4.py:324, no copy)
         logits = self.head.logits(p1, p2, p3)
         layers = (self.head.yolo1[2], self.head.yolo2[2], self.head.yolo3[2])
