@@ -48,6 +48,11 @@ def main():
             if MODE == 'dgrad':
                 arms = {'regstage': lambda: ops.conv_dgrad_raw(dy, w, (B, ci, H, H), k, s, dy_amax=da),
                         'planes': lambda: ops.conv_dgrad_planes_raw(dyp, w, (B, ci, H, H), k)}
+            elif MODE == 'dgrad_res':
+                # skip-operand epilogue: 'regstage' column = the plane kernel WITHOUT a residual, 'planes' = with one
+                res = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+                arms = {'regstage': lambda: ops.conv_dgrad_planes_raw(dyp, w, (B, ci, H, H), k),
+                        'planes': lambda: ops.conv_dgrad_planes_raw(dyp, w, (B, ci, H, H), k, residual=res)}
             else:
                 arms = {'regstage': lambda: ops.conv_wgrad_raw(x, dy, (co, ci, k, k), k, s, x_amax=xa, dy_amax=da),
                         'planes': lambda: ops.conv_wgrad_planes_raw(xp, dyp, (co, ci, k, k), k)}

@@ -39,7 +39,7 @@ def _loss(m, x, labels, dev):
     loss = crit(m(x), {'padded_labels': labels})
     loss.backward()
     torch.cuda.synchronize()
-    return float(loss)
+    return float(loss.detach())
 
 
 WATCHED = [

@@ -274,20 +274,47 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                                                         g.res ? (unsigned)(rby < 0xfffffff0ull ? rby : 0xfffffff0ull) : 0u);
         const int colb = n0 + wn * WTN + fr;
         const bool allc = n0 + BN <= g.N;
+        if (g.res) {
+            // skip operand (dgrad: the gradient arriving over a ResBlock skip connection): the 4 x TN loads of a row tile all go
+            // out before the first of them is needed -- issued one by one in front of their stores, each store waited for
+            // its own dependent load (128->128 1x1 @76^2 dgrad ran at half its forward rate)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned rl = (unsigned)(wm * WTM + 16 * i + 4 * kq);
-            const unsigned dvo = rl * drow + (unsigned)colb * 4u, rvo = rl * rrow + (unsigned)colb * 4u;
+            for (int i = 0; i < TM; ++i) {
+                const unsigned rl = (unsigned)(wm * WTM + 16 * i + 4 * kq);
+                const unsigned dvo = rl * drow + (unsigned)colb * 4u, rvo = rl * rrow + (unsigned)colb * 4u;
+                float rv[4][TN];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
-                    acc0[i][j][e] = v;                     // kept for the column sums
-                    const bool cok = allc || colb + 16 * j < g.N;
-                    if (g.res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(cok ? rvo + 64u * j : 0xffffffffu), (int)(e * rrow), 0));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
-                }
+                    for (int j = 0; j < TN; ++j) {
+                        const bool cok = allc || colb + 16 * j < g.N;
+                        rv[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(cok ? rvo + 64u * j : 0xffffffffu), (int)(e * rrow), 0));
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                        acc0[i][j][e] = v;                 // kept for the column sums
+                        const bool cok = allc || colb + 16 * j < g.N;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rv[e][j]), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned rl = (unsigned)(wm * WTM + 16 * i + 4 * kq);
+                const unsigned dvo = rl * drow + (unsigned)colb * 4u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                        acc0[i][j][e] = v;                 // kept for the column sums
+                        const bool cok = allc || colb + 16 * j < g.N;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
+                    }
+            }
         }
     }
     if (g.stats) {                                         // rows past M are exact zeros (their operand rows were zero-filled)
