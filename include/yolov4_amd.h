@@ -241,6 +241,8 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
  * for any sample of M values, |act(v)| <= |v|, so |z| <= max_c(|gamma_c| sqrt(M - 1) + |beta_c|) + max|residual|
  * (res_amax: the residual's maximum word, required with a residual) -- and leaves it in *out_amax for the consumers.  A
  * loose bound costs the split only headroom (full precision down to 2^-29 of the bound).
+ * z_planes == 3 (conv mode 2, bf16 MFMA conv): z receives plain bf16 values (RN), dense per pixel in the FIRST HALF of the
+ * fp32-sized row (ldz == C: the row pitch stays 4 C bytes, the second half is not touched); out_amax is not used.
  * planes_twin (nullable, with z_planes != 0): z stays fp32 (pitch ldz) and planes_twin [M][C] receives the pre-split copy --
  * for a tensor that feeds both a plane-consuming conv and fp32 consumers (a fork in front of a detection head). */
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
@@ -259,8 +261,10 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                          plane conv kernels (layout as y4_bn_act_fwd_f32 z_planes; lddy == C, C % 32 == 0), scaled by a
                          bound of max|dy| derived before the sweep; word [5] receives that bound and serves as dy_amax
                          of y4_conv2d_dgrad_planes_f32 / y4_conv2d_wgrad_planes_f32 */,
-                      int frozen_stats /* != 0: mean / invstd are constants (eval-mode BatchNorm under autograd: running
-                         statistics), so dy = gamma invstd g without the two batch-statistic terms; dgamma / dbeta as usual */,
+                      int frozen_stats /* bit 0: mean / invstd are constants (eval-mode BatchNorm under autograd: running
+                         statistics), so dy = gamma invstd g without the two batch-statistic terms; dgamma / dbeta as usual.
+                         bit 1 (conv mode 2): dy leaves as plain bf16 in the first half of each fp32-sized row, as
+                         y4_bn_act_fwd_f32 z_planes == 3 (lddy == C, C % 32 == 0, f16_planes NULL) */,
                       void* stream);
 /* dbias[c] = sum_m dy[m,c]  (bias=True head convs, yolov4.py:237,243,249): two fixed-order stages, no atomics
  * (deterministic).  workspace: y4_bias_grad_workspace(M, C) bytes */

@@ -212,3 +212,112 @@ def test_forward_call_prepares_the_dgrad_filter(dev, case):
     assert torch.equal(dx_a, dx_b)
     ref = torch.nn.grad.conv2d_input((B, ci, H, H), w.double().cpu(), dy.double().cpu(), s, (k - 1) // 2)
     assert float((dx_b.double().cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+
+
+# ---------------------------------------------------------------- conv mode 2: the same kernels over plain bf16 operands
+BF16_CASES = [
+    # B, Cin, Cout, k, s, H, W
+    (2, 64, 128, 3, 1, 9, 9),          # M = 162 < one tile
+    (3, 64, 128, 3, 2, 13, 13),        # odd size, stride 2 (forward only)
+    (2, 128, 128, 1, 1, 12, 12),       # K = 128: the 128-row shape
+    (5, 512, 256, 1, 1, 7, 7),         # tiles span several images; N = 256
+    (2, 128, 256, 3, 1, 19, 19),       # M = 722 (ragged)
+    (2, 2048, 512, 1, 1, 5, 5),
+    (3, 256, 512, 3, 1, 19, 19),       # 256 x 256 tiles, ragged M = 1083
+    (2, 64, 192, 1, 1, 20, 20),        # N not a multiple of 128
+]
+
+
+def _bf(t):
+    return t.bfloat16().double()
+
+
+@pytest.fixture()
+def bf16_mode(dev):
+    import yolov4_amd
+    old = yolov4_amd.get_conv_mode()
+    yolov4_amd.set_conv_mode('bf16')
+    yield
+    yolov4_amd.set_conv_mode(old)
+
+
+@pytest.mark.parametrize('tile', ['0', '1', '2'])
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_bf16_planes_forward_dgrad_wgrad_are_exact_bf16_products(dev, bf16_mode, case, tile, monkeypatch):
+    """BASELINE configs[4] (bf16 MFMA conv): operands rounded to bf16 (RN) by the producers, products exact in fp32, fp32
+    accumulation -> against torch fp64 on the SAME bf16-rounded operands the only difference is the accumulation order:
+    2e-6 of the range, forward / dgrad / wgrad, every tile shape the dispatcher may choose (Y4_BF_TILE is read once per
+    process, so the three values are three parametrisations of the first call only; the default run covers the heuristic)."""
+    from yolov4_amd import ops
+    B, ci, co, k, s, H, W = case
+    x = recipe.randn((B, ci, H, W), 7)
+    w = recipe.randn((co, ci, k, k), 8, 1.0 / np.sqrt(ci * k * k))
+    ref = F.conv2d(_bf(x), _bf(w), None, s, (k - 1) // 2)
+    xd, wd = cl(x, dev), cl(w, dev)
+    xp = ops.planes_split_raw(xd)
+    assert xp.amax is None
+    y, part, n = ops.conv_fwd_planes_raw(xp, wd, k, s)
+    torch.cuda.synchronize()
+    assert 'true>' in ops.last_conv_kernel(), ops.last_conv_kernel()
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    # column sums of the epilogue = sums of the stored result
+    st = part.view(torch.float32)[:n * 2 * co].view(n, 2, co).double().sum(0).cpu()
+    yf = y.double().cpu().permute(0, 2, 3, 1).reshape(-1, co)
+    assert float((st[0] - yf.sum(0)).abs().max()) <= 1e-4 * max(float(yf.abs().sum(0).max()), 1e-6)
+    assert float((st[1] - (yf * yf).sum(0)).abs().max()) <= 1e-4 * float((yf * yf).sum(0).max())
+    if s != 1:
+        return
+    dy = recipe.randn((B, co, H, W), 9)
+    dyd = cl(dy, dev)
+    dyp = ops.planes_split_raw(dyd)
+    res = cl(recipe.randn((B, ci, H, W), 10), dev)
+    dx = ops.conv_dgrad_planes_raw(dyp, wd, (B, ci, H, W), k, residual=res)
+    dw = ops.conv_wgrad_planes_raw(xp, dyp, (co, ci, k, k), k)
+    torch.cuda.synchronize()
+    dx_ref = torch.nn.grad.conv2d_input((B, ci, H, W), _bf(w), _bf(dy), s, (k - 1) // 2) + res.double().cpu()
+    dw_ref = torch.nn.grad.conv2d_weight(_bf(x), (co, ci, k, k), _bf(dy), s, (k - 1) // 2)
+    assert float((dx.double().cpu() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+    assert float((dw.double().cpu() - dw_ref).abs().max()) <= 2e-6 * float(dw_ref.abs().max())
+
+
+def test_bf16_chain_and_resblock_through_planes_match_the_register_staged_bf16_path(dev, bf16_mode):
+    """Training-mode chains in conv mode 2 with pre-split (bf16) intermediates against the same modules with PLANES off (fp32
+    tensors in HBM, rounded to bf16 while staged by the mode-2 register-staged kernels): the SAME bf16 operands reach the
+    MFMAs either way, so results agree to accumulation order -- except that a dy rounded to bf16 by the BatchNorm backward
+    sweep is also what wgrad sees, as in the other arm."""
+    from yolov4_amd import ops
+    from yolov4_amd.darknet.darknet import ConvBNAct, ResBlock, chain, takes_planes
+    from torch import nn
+    torch.manual_seed(21)
+    seq = nn.Sequential(ConvBNAct(256, 128, 1, 1, act='leaky_relu'), ConvBNAct(128, 256, 3, 1, act='leaky_relu'),
+                        ConvBNAct(256, 128, 1, 1, act='leaky_relu'), ConvBNAct(128, 256, 3, 1, act='leaky_relu'),
+                        ConvBNAct(256, 128, 1, 1, act='leaky_relu')).to(dev).train()
+    rb = ResBlock(128, num_blocks=2).to(dev).train()
+    for m in list(seq.modules()) + list(rb.modules()):
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+    x = torch.randn(3, 256, 19, 19, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(3, 128, 19, 19, device=dev).contiguous(memory_format=torch.channels_last)
+    assert takes_planes(seq[1]) and takes_planes(seq[2])
+
+    def run(on):
+        ops.PLANES['on'] = on
+        for p in list(seq.parameters()) + list(rb.parameters()):
+            p.grad = None
+        x.grad = None
+        out = rb(chain(seq, x))
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(seq.parameters()) + list(rb.parameters())]
+    was = ops.PLANES['on']
+    try:
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+    finally:
+        ops.PLANES['on'] = was
+    assert float((o1 - o0).abs().max()) <= 2e-4 * float(o0.abs().max())
+    assert float((gx1 - gx0).abs().max()) <= 2e-3 * float(gx0.abs().max())
+    for a, b in zip(gp1, gp0):
+        assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-6)

@@ -78,11 +78,12 @@ int f16x2_tile_dgrad_s2(const ConvGeom& g, hipStream_t st);      // dgrad of a s
 bool planes_conv_ok(int Cin, int Cout, int k, int stride);
 int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,
                 const float* res, long long ldr, float* stats, int* nparts, int B, int Hs, int Ws, int Cs, int N, int k, int stride,
-                hipStream_t st);
-int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st);
-void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps);
+                hipStream_t st, bool bf = false);
+int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st, bool bf = false);
+void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn = 128);
+int planes_wgrad_tn(int Cout, bool bf);
 int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const unsigned* dy_amax, float* dw, void* workspace,
-                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st);
+                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st, bool bf = false);
 
 // Name of the conv kernel launched last on this host thread, spelled as rocprofv3 prints the symbol (bench.py names the
 // dominant kernel with it instead of restating the dispatch rules).

@@ -58,12 +58,29 @@ constexpr int PROW = 128;                                  // bytes per LDS row:
 //   <128, 128, 2, 2>: 4 waves, two 32-KB stages, TWO blocks per CU -- short-K layers (1x1 with K <= a few hundred), which
 //                     are HBM-bound: with one block per CU its load, MFMA and store phases run back to back and the
 //                     memory pipes idle for most of them; two co-resident blocks overlap one's epilogue with the other's loads.
-template <int BM, int BN, int WM, int WN>
+//
+// BF (conv mode 2, BASELINE configs[4]: bf16 MFMA conv, fp32 everything else): the SAME kernel over plain bf16 operands.
+// A 128-B row then holds 64 channels of one pixel (activations: dense bf16 NHWC in the first half of the fp32-sized row,
+// filters: the dense bf16 [N][K] matrix), a K-tile is 64 deep, the two 16-B chunks a lane reads per row are k 0-31 and
+// k 32-63 of ONE plane: two bf16 MFMAs into ONE accumulator set, no scales.  With half the accumulator registers the wave
+// tile grows to 128 x 64 (<256, 256, 2, 4>: two 64-KB stages), which brings the staged bytes per MFMA cycle back to the
+// f16x2 kernel's (32 B / clk / CU) -- at 256 x 128 the bf16 form would wait for its DMA most of the time.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <bool BF>
+__device__ __forceinline__ f32x4v pl_mma(const f16x8 a, const f16x8 b, const f32x4v c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, bool BF>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_planes_mfma(const PlaneConvGeom g) {
     constexpr int NWAVE = WM * WN, NTHR = NWAVE * 64;
     static_assert(NWAVE == 8 || NWAVE == 4, "8 or 4 waves");
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 16, TN = WTN / 16;
-    constexpr int A_BYTES = BM * PROW, B_BYTES = BN * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = NWAVE == 8 ? 3 : 2;
+    constexpr int A_BYTES = BM * PROW, B_BYTES = BN * PROW, STAGE = A_BYTES + B_BYTES;
+    constexpr int NSTAGE = (NWAVE == 8 && 3 * STAGE <= 160 * 1024) ? 3 : 2;
+    constexpr int KSH = BF ? 6 : 5;                        // log2 of the channels in one 128-B row
+    constexpr unsigned WEB = BF ? 2u : 4u;                 // filter bytes per element
     constexpr int PA = BM / 8 / NWAVE, PB = BN / 8 / NWAVE, NDMA = PA + PB;      // 1-KiB DMA pieces per wave and K-tile
     static_assert(PA >= 1 && PB >= 1 && ((NSTAGE == 3 && NDMA == 6) || (NSTAGE == 2 && NDMA == 8)),
                   "the counted vmcnt below assumes 6 (three stages) or 8 (two stages) pieces per wave and K-tile");
@@ -76,7 +93,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
     const int lt = y4_xcd_remap(blockIdx.x, g.mtiles * g.ntiles);
     const int mt = lt / g.ntiles, nt = lt - mt * g.ntiles;
     const int n0 = nt * BN;
-    const int CC = g.Cs >> 5;
+    const int CC = g.Cs >> KSH;
     const int KT = g.k * g.k * CC;
 
     // ---- 32-bit window of the source tensor, re-based at the first image this tile touches
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
     for (int j = 0; j < PB; ++j) {
         const int row = (wave * PB + j) * 8 + lr;
         const int chunk = pos ^ ((row >> 1) & 7);
-        b_off[j] = (n0 + row) < g.N ? (unsigned)(n0 + row) * (unsigned)g.K * 4u + (unsigned)chunk * 16u : OOB;
+        b_off[j] = (n0 + row) < g.N ? (unsigned)(n0 + row) * (unsigned)g.K * WEB + (unsigned)chunk * 16u : OOB;
     }
     // ---- DMA issue state: the K-tile (ld_tap, ld_cc) whose pieces are going out next; taps outer, channel chunks inner
     int ld_tap = 0, ld_r = 0, ld_q = 0, ld_cc = 0;
@@ -152,13 +169,16 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
     using I0 = std::integral_constant<int, 0>; using I2 = std::integral_constant<int, 2>; using I4 = std::integral_constant<int, 4>;
     using I6 = std::integral_constant<int, NDMA>;          // (= all pieces of a K-tile)
 
-    accv acc0[TM][TN], acc1[TM][TN];
+    accv acc0[TM][TN], acc1[BF ? 1 : TM][BF ? 1 : TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+            for (int e = 0; e < 4; ++e) {
+                acc0[i][j][e] = 0.f;
+                if constexpr (!BF) acc1[i][j][e] = 0.f;
+            }
 
     // ---- fragment addresses: lane -> (row fr of a 16-row tile, K quarter kq); logical chunks kq (hi) and 4 + kq (lo)
     const int fr = lane & 15, kq = lane >> 4;
@@ -214,11 +234,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                     }
                 }
             }
+            if constexpr (BF) {                            // k 0-31, then k 32-63: TN independent MFMAs between the dependent pair
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[j][0], acc1[i][j], 0, 0, 0);
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
-                acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc0[i][j] = pl_mma<true>(fa0, fb[j][0], acc0[i][j]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc0[i][j] = pl_mma<true>(fa1, fb[j][1], acc0[i][j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = pl_mma<false>(fa1, fb[j][0], acc1[i][j]);
+                    acc1[i][j] = pl_mma<false>(fa0, fb[j][1], acc1[i][j]);
+                    acc0[i][j] = pl_mma<false>(fa0, fb[j][0], acc0[i][j]);
+                }
             }
             if constexpr (NSTAGE == 3) {
                 if (i == 0 && pend) issue((S + 2) % NSTAGE, I2{}, I4{});
@@ -262,8 +289,12 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
     // column in the vector offset, the accumulator register e in the scalar offset, the column tile j as the immediate.
     // 1-4 % faster on every layer shape than passing the tile through per-wave LDS patches to store float4 rows (A/B on
     // one box), and it leaves the stage memory alone.
-    const float un = pl_unscale(g.src_amax) * pl_unscale(g.wt_amax);
+    const float un = BF ? 1.0f : pl_unscale(g.src_amax) * pl_unscale(g.wt_amax);
     const float un1 = un * (1.0f / 2048.0f);
+    auto result = [&](int i, int j, int e) -> float {
+        if constexpr (BF) return acc0[i][j][e];
+        else return acc0[i][j][e] * un + acc1[i][j][e] * un1;
+    };
     {
         const unsigned drow = (unsigned)g.ldd * 4u, rrow = (unsigned)g.ldr * 4u;
         const long long row0 = (long long)mt * BM;
@@ -294,7 +325,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                        const float v = result(i, j, e);
                         acc0[i][j][e] = v;                 // kept for the column sums
                         const bool cok = allc || colb + 16 * j < g.N;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rv[e][j]), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
@@ -309,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        const float v = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+                        const float v = result(i, j, e);
                         acc0[i][j][e] = v;                 // kept for the column sums
                         const bool cok = allc || colb + 16 * j < g.N;
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
@@ -385,15 +416,30 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* p) {      // k 0..
     return r;
 }
 
-template <int TN_, int TJ_>
+template <int N> __device__ __forceinline__ void pl_wait_vm() {      // counted wait with a compile-time literal
+    static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12, "add the literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// BF (conv mode 2): plain bf16 operands.  A 128-B LDS row is then one pixel's 64-channel chunk, its four 32-B segments are
+// four 16-channel tiles of ONE plane (f16x2: [hi 0-15 | hi 16-31 | lo 0-15 | lo 16-31]), one bf16 MFMA per tile pair and
+// K-step into one accumulator set; <128, 256>: 24 KB per K-step, <256, 256> (wave tile 128 x 64): 32 KB per K-step, the f16x2
+// kernel's bytes per MFMA cycle.  The result leaves through raw buffer stores (the LDS patches of the f16x2 form do not fit).
+template <int TN_, int TJ_, bool BF>
 __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom g) {
     constexpr int NWAVE = 8, WN2 = 2, WJ = 4;
     constexpr int BAR = 2;                                 // row tile in front of whose MFMAs the barrier sits (see `step`)
+    constexpr int CH = BF ? 64 : 32, CSH = BF ? 6 : 5;     // channels per 128-B row
     constexpr int WTN = TN_ / WN2, WTJ = TJ_ / WJ, TM = WTN / 16, TN = WTJ / 16;
-    static_assert(TM == 4 && TN == 4, "wave tile 64 x 64");
-    constexpr int A_BYTES = (TN_ / 32) * 32 * PROW, B_BYTES = (TJ_ / 32) * 32 * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
+    static_assert(TN == 4 && (TM == 4 || (BF && TM == 8)), "wave tile 64 x 64 (bf16 also 128 x 64)");
+    constexpr int A_BYTES = (TN_ / CH) * 32 * PROW, B_BYTES = (TJ_ / CH) * 32 * PROW, STAGE = A_BYTES + B_BYTES, NSTAGE = 3;
     constexpr int PA = A_BYTES / 1024 / NWAVE, PB = B_BYTES / 1024 / NWAVE, NDMA = PA + PB;
-    static_assert(PA == 2 && PB == 4 && NDMA == 6, "6 DMA pieces per wave and K-step");
+    static_assert(PA >= 1 && PB >= 1 && (NDMA == 6 || NDMA == 3 || NDMA == 4), "DMA pieces per wave and K-step (counted vmcnt literals)");
     typedef float accv __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
@@ -406,7 +452,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
     bid -= split * tiles;
     const int tn = bid / g.ntj, tj = bid - tn * g.ntj;
     const int n0 = tn * TN_, j0 = tj * TJ_;
-    const int CC = g.Cin >> 5;
+    const int CC = g.Cin >> CSH;
 
     const int steps_total = (g.M + 31) >> 5;
     const int s0 = split * g.steps_per_split;
@@ -436,7 +482,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
         const int chunk = a >> 2, p = (a & 3) * 8 + lr;
         const int gsw = ((p >> 1) & 1) | (((p >> 3) & 1) << 1);
         const unsigned srcoff = (unsigned)((((pos >> 1) ^ gsw) << 5) + ((pos & 1) << 4));
-        a_voff[i] = (n0 + chunk * 32) < g.Cout ? (unsigned)p * pitch_dy + (unsigned)(n0 / 32 + chunk) * 128u + srcoff : OOB;
+        a_voff[i] = (n0 + chunk * CH) < g.Cout ? (unsigned)p * pitch_dy + (unsigned)(n0 / CH + chunk) * 128u + srcoff : OOB;
     }
     // x pieces: pixel octet wave & 3, j chunks (wave >> 2) * 4 + i: ONE pixel per lane, four taps / channel chunks
     const int xp = (wave & 3) * 8 + lr;                    // pixel of this lane inside the K-step
@@ -447,8 +493,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
         const unsigned srcoff = (unsigned)((((pos >> 1) ^ gsw) << 5) + ((pos & 1) << 4));
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            const int jg = j0 / 32 + (wave >> 2) * PB + i;
-            const bool ok = jg * 32 < g.J;
+            const int jg = j0 / CH + (wave >> 2) * PB + i;
+            const bool ok = jg * CH < g.J;
             const int tap = ok ? jg / CC : 0;
             const int c32 = jg - tap * CC;
             const int r = tap / g.k, q = tap - r * g.k;
@@ -494,13 +540,16 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
     using I0 = std::integral_constant<int, 0>;
     using I6 = std::integral_constant<int, NDMA>;          // (= all pieces of a K-tile)
 
-    accv acc0[TM][TN], acc1[TM][TN];
+    accv acc0[TM][TN], acc1[BF ? 1 : TM][BF ? 1 : TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+            for (int e = 0; e < 4; ++e) {
+                acc0[i][j][e] = 0.f;
+                if constexpr (!BF) acc1[i][j][e] = 0.f;
+            }
 
     // ---- transposed fragment reads: lane -> (k group grp: pixels 8 grp + {0..3} and + 4, block row qrow, 8-B piece pp)
     const int grp = lane >> 4, qrow = (lane >> 2) & 3, pp = lane & 3;
@@ -510,39 +559,44 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
     int segoff[4];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) segoff[s4] = rowoff + ((s4 ^ gsw) << 5);
-    const int a_tile0 = (wn2 * (WTN / 32)) * 32 * PROW;                // chunk of this wave's first n tile
-    const int b_tile0 = A_BYTES + (wj * (WTJ / 32)) * 32 * PROW;
+    const int a_tile0 = (wn2 * (WTN / CH)) * 32 * PROW;                // chunk of this wave's first n tile
+    const int b_tile0 = A_BYTES + (wj * (WTJ / CH)) * 32 * PROW;
+    // 16-channel tile t of a wave's range, plane pl (f16x2 only) -> offset of its fragment inside the operand's stage image
+    auto frag_off = [&](int t, int pl) -> int {
+        if constexpr (BF) return (t >> 2) * 32 * PROW + segoff[t & 3];
+        else return (t >> 1) * 32 * PROW + segoff[2 * pl + (t & 1)];
+    };
+    constexpr int NPL = BF ? 1 : 2;
 
     auto step = [&](auto SC, const int kt) {
         constexpr int S = decltype(SC)::value;
         const unsigned char* base = smem + S * STAGE;
-        f16x8 fb[TN][2];
+        f16x8 fb[TN][NPL];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            fb[j][0] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[0 + (j & 1)]);
-            fb[j][1] = tr_frag(base + b_tile0 + (j >> 1) * 32 * PROW + segoff[2 + (j & 1)]);
-        }
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) fb[j][pl] = tr_frag(base + b_tile0 + frag_off(j, pl));
         // A fragments ahead of their MFMAs: row tile i + 1 is requested before the MFMAs of row tile i; at the barrier
         // position BAR everything still missing is requested, so that the stage goes back to the DMA 24 MFMAs before the step
         // ends (BAR = 3 -> 2: +5...9 %; BAR = 1 or 0 need three / four fragment sets live and spill inside the loop: 1.6x slower)
-        f16x8 fap[TM][2];
-        fap[0][0] = tr_frag(base + a_tile0 + segoff[0]);
-        fap[0][1] = tr_frag(base + a_tile0 + segoff[2]);
+        f16x8 fap[TM][NPL];
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) fap[0][pl] = tr_frag(base + a_tile0 + frag_off(0, pl));
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = i + 1; r < TM; ++r)
                 if ((i < BAR && r == i + 1) || (i == BAR && r > i)) {
-                    fap[r][0] = tr_frag(base + a_tile0 + (r >> 1) * 32 * PROW + segoff[0 + (r & 1)]);
-                    fap[r][1] = tr_frag(base + a_tile0 + (r >> 1) * 32 * PROW + segoff[2 + (r & 1)]);
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) fap[r][pl] = tr_frag(base + a_tile0 + frag_off(r, pl));
                 }
-            const f16x8 fa0 = fap[i][0], fa1 = fap[i][1];
+            const f16x8 fa0 = fap[i][0], fa1 = fap[i][NPL - 1];
             if (i == BAR) {
                 __builtin_amdgcn_sched_barrier(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (kt + 1 < KT) {
-                    if (kt + 2 < KT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (kt + 2 < KT) pl_wait_vm<NDMA>();
+                    else pl_wait_vm<0>();
                     __builtin_amdgcn_s_barrier();
                     // all six pieces of tile t + 3 at once, the moment its stage is free: this kernel streams fresh pixels every
                     // K-step and waits for them (with the DMA switched off it runs 1.4-1.8x faster), so two whole steps of lead
@@ -550,19 +604,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
                     if (kt + 3 < KT) issue(S, I0{}, I6{});
                 }
             }
+            if constexpr (BF) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb[j][0], acc1[i][j], 0, 0, 0);
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][1], acc1[i][j], 0, 0, 0);
-                acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb[j][0], acc0[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc0[i][j] = pl_mma<true>(fa0, fb[j][0], acc0[i][j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc1[i][j] = pl_mma<false>(fa1, fb[j][0], acc1[i][j]);
+                    acc1[i][j] = pl_mma<false>(fa0, fb[j][NPL - 1], acc1[i][j]);
+                    acc0[i][j] = pl_mma<false>(fa0, fb[j][0], acc0[i][j]);
+                }
             }
         }
     };
 
     for (int t = 0; t < 3 && t < KT; ++t) issue(t, I0{}, I6{});
-    if (KT >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (KT == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (KT >= 3) pl_wait_vm<2 * NDMA>();
+    else if (KT == 2) pl_wait_vm<NDMA>();
+    else pl_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     {
         int kt = 0;
@@ -575,12 +634,33 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
         if (kt + 1 < KT) step(std::integral_constant<int, 1>{}, kt + 1);
     }
 
+    if constexpr (BF) {
+        // ---- epilogue (bf16): raw buffer stores straight from the accumulators; a wave instruction writes 4 rows x 64 B
+        float* outb = g.out + (long long)split * g.Cout * g.J;
+        const __amdgpu_buffer_rsrc_t ors = y4_make_rsrc(outb, (unsigned)((unsigned long long)g.Cout * g.J * 4ull));
+        int lane_b = lane;
+        asm volatile("" : "+v"(lane_b));
+        const int frb = lane_b & 15, kqb = lane_b >> 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + wn2 * WTN + i * 16 + 4 * kqb + e;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int jj = j0 + wj * WTJ + j * 16 + frb;
+                    const unsigned off = (n < g.Cout && jj < g.J) ? ((unsigned)n * (unsigned)g.J + (unsigned)jj) * 4u : 0xffffffffu;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc0[i][j][e]), ors, (int)off, 0, 0);
+                }
+            }
+        return;
+    }
     // ---- epilogue: out[n][j] = (acc0 + 2^-11 acc1) / (s_dy s_x), through per-wave LDS patches as float4 rows of j
     const float un = pl_unscale(g.dy_amax) * pl_unscale(g.x_amax);
     const float un1 = un * (1.0f / 2048.0f);
     __syncthreads();
     constexpr int EP = WTJ + 4;
-    static_assert(NWAVE * WTN * EP * 4 <= NSTAGE * STAGE, "epilogue patches must fit the stages");
+    static_assert(BF || NWAVE * WTN * EP * 4 <= NSTAGE * STAGE, "epilogue patches must fit the stages");
     float* patch = reinterpret_cast<float*>(smem) + wave * (WTN * EP);
     // the epilogue's lane arithmetic starts from an opaque copy of the lane id: otherwise the compiler forms these addresses
     // before the K loop, where every one of the 256 registers is taken, and parks them in scratch
@@ -592,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) patch[(i * 16 + 4 * kq + e) * EP + j * 16 + fr] = acc0[i][j][e] * un + acc1[i][j][e] * un1;
+            for (int e = 0; e < 4; ++e) patch[(i * 16 + 4 * kq + e) * EP + j * 16 + fr] = acc0[i][j][e] * un + acc1[BF ? 0 : i][BF ? 0 : j][e] * un1;
     float* out = g.out + (long long)split * g.Cout * g.J;
     const int c4 = (lane_e & 15) * 4;
     const int jv = j0 + wj * WTJ + c4;
@@ -629,18 +709,64 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+// ---- conv mode 2 (bf16): the "planes" of an activation are its bf16 values, dense per pixel in the FIRST HALF of the fp32-sized
+// row (pitch 4 C bytes: same allocation, same addressing as the f16x2 planes; the second half is never touched)
+__device__ __forceinline__ unsigned short pl_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__global__ __launch_bounds__(256) void planes_split_bf16_kernel(const float* __restrict__ x, long long ld, long long M, int C,
+                                                                unsigned char* __restrict__ planes) {
+    const int C4 = C >> 2;
+    const long long total = M * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / C4;
+        const int c = (int)(i - m * C4) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ld + c);
+        typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+        us4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pl_bf16_bits(v[e]);
+        *reinterpret_cast<us4*>(planes + m * (long long)C * 4 + c * 2) = o;
+    }
+}
+// filter [Cout][kk][Cin] fp32 -> bf16, same order (forward operand), and optionally [Cin][kk (mirrored)][Cout] (dgrad operand)
+__global__ __launch_bounds__(256) void bf16_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ fwd,
+                                                          unsigned short* __restrict__ tr, int Cout, int Cin, int kk, int mirror) {
+    const long long n = (long long)Cout * kk * Cin;
+    const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    if (fwd)
+        for (long long i = i0; i < n; i += step) fwd[i] = pl_bf16_bits(w[i]);
+    if (tr)
+        for (long long i = i0; i < n; i += step) {
+            const int nn = (int)(i % Cout);
+            const long long t = i / Cout;
+            const int tp = (int)(t % kk);
+            const int tap = mirror ? kk - 1 - tp : tp;
+            const int c = (int)(t / kk);
+            tr[i] = pl_bf16_bits(w[((long long)nn * kk + tap) * Cin + c]);
+        }
+}
+int bf16_filter(const float* w, unsigned short* fwd, unsigned short* tr, int Cout, int Cin, int kk, bool mirror, hipStream_t st) {
+    const long long n = (long long)Cout * kk * Cin;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(bf16_filter_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, w, fwd, tr, Cout, Cin, kk, mirror ? 1 : 0);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool BF>
 int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     PlaneConvGeom g = g0;
     g.mtiles = (g.M + BM - 1) / BM;
     g.ntiles = (g.N + BN - 1) / BN;
     constexpr int NW = WM * WN;
-    constexpr size_t smem = (NW == 8 ? 3ull : 2ull) * (BM + BN) * PROW;     // the stages; the epilogue needs WM * BN * 8 B of them
+    constexpr size_t stage = (size_t)(BM + BN) * PROW;
+    constexpr size_t smem = ((NW == 8 && 3 * stage <= 160 * 1024) ? 3ull : 2ull) * stage;   // the stages; the epilogue needs WM * BN * 8 B of them
     static_assert(NW == 8 || 2 * smem <= 160 * 1024, "two blocks per CU");
-    auto kern = conv_planes_mfma<BM, BN, WM, WN>;
+    static_assert(smem <= 160 * 1024, "LDS");
+    auto kern = conv_planes_mfma<BM, BN, WM, WN, BF>;
     static Y4DynLds lds_attr;                              // per device, see common.h
     if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
-    y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d>", BM, BN, WM, WN);
+    if (BF) y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d, true>", BM, BN, WM, WN);
+    else y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d, false>", BM, BN, WM, WN);
     hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -655,10 +781,10 @@ bool planes_conv_ok(int Cin, int Cout, int k, int stride) {
 }
 
 // forward-form conv over planes: src [B][Hs][Ws][Cs] planes, filter planes [N][k*k*Cs], raw fp32 result (+ res) and
-// optional per-M-tile column sums (256-row tiles)
+// optional per-M-tile column sums (256-row tiles).  bf: plain bf16 operands (conv mode 2), amax words unused.
 int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,
                 const float* res, long long ldr, float* stats, int* nparts, int B, int Hs, int Ws, int Cs, int N, int k, int stride,
-                hipStream_t st) {
+                hipStream_t st, bool bf) {
     PlaneConvGeom g{};
     const int pad = (k - 1) / 2;
     g.src = static_cast<const unsigned char*>(src); g.wt = static_cast<const unsigned char*>(wt_planes);
@@ -668,9 +794,10 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
     g.Wd = (Ws + 2 * pad - k) / stride + 1;
     const long long M = (long long)B * g.Hd * g.Wd;
     if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
+    if (bf && (Cs & 63)) return Y4_ERR_SHAPE;              // whole 64-channel K tiles
     g.M = (int)M; g.K = k * k * Cs;
     const unsigned long long img = (unsigned long long)Hs * Ws * (unsigned long long)Cs * 4ull;
-    const unsigned long long wb = (unsigned long long)N * g.K * 4ull;
+    const unsigned long long wb = (unsigned long long)N * g.K * (bf ? 2ull : 4ull);
     // a 256-row tile may span several images: the 32-bit window starts at the first one
     const unsigned long long imgs_per_tile = 256ull / (unsigned long long)(g.Hd * g.Wd > 0 ? g.Hd * g.Wd : 1) + 2;
     if (img * imgs_per_tile >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;
@@ -681,15 +808,28 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
     // on the 256-row shape wins again).  Y4_PLANES_SMALL = 0 never, 2 always (experiments)
     static const int small_mode = getenv("Y4_PLANES_SMALL") ? atoi(getenv("Y4_PLANES_SMALL")) : 1;
     const bool small = small_mode == 2 || (small_mode == 1 && g.K <= 256);
+    if (bf) {
+        // 256 x 256 (wave tile 128 x 64) unless its grid quantises badly on 256 CUs or N fits one 128-column tile
+        static const int bf_tile = getenv("Y4_BF_TILE") ? atoi(getenv("Y4_BF_TILE")) : 0;     // 1: 256x128 always, 2: 256x256 always
+        const long long mt = (g.M + 255) / 256;
+        const long long r256 = (mt * ((N + 255) / 256) + 255) / 256, r128 = (mt * ((N + 127) / 128) + 255) / 256;
+        const bool big = bf_tile == 2 || (bf_tile == 0 && N > 128 && (double)r256 * 2.0 <= (double)r128 * 1.25);
+        if (small && !big) {
+            if (nparts) *nparts = (g.M + 127) / 128;
+            return launch_conv_planes<128, 128, 2, 2, true>(g, st);
+        }
+        if (nparts) *nparts = (g.M + 255) / 256;
+        return big ? launch_conv_planes<256, 256, 2, 4, true>(g, st) : launch_conv_planes<256, 128, 4, 2, true>(g, st);
+    }
     if (nparts) *nparts = small ? (g.M + 127) / 128 : (g.M + 255) / 256;
-    return small ? launch_conv_planes<128, 128, 2, 2>(g, st) : launch_conv_planes<256, 128, 4, 2>(g, st);
+    return small ? launch_conv_planes<128, 128, 2, 2, false>(g, st) : launch_conv_planes<256, 128, 4, 2, false>(g, st);
 }
 
 // split-K plan of the plane wgrad: tiles x splits blocks on 256 CUs (one block per CU), minimising rounds x K-steps per block
-void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps) {
+void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn) {
     const long long M = (long long)B * H * W;
     const int J = k * k * Cin;
-    *ntn = (Cout + 127) / 128;
+    *ntn = (Cout + tn - 1) / tn;
     *ntj = (J + 255) / 256;
     const int tiles = *ntn * *ntj;
     const long long steps = (M + 31) / 32;
@@ -706,15 +846,40 @@ void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, 
     *splits = (int)((steps + per - 1) / per);
 }
 
+// bf16 form: 256-row n tiles (wave tile 128 x 64) when Cout fills them
+int planes_wgrad_tn(int Cout, bool bf) {
+    static const int bf_tile = getenv("Y4_BF_WGRAD_TILE") ? atoi(getenv("Y4_BF_WGRAD_TILE")) : 0;     // 128 / 256: forced
+    if (!bf) return 128;
+    if (bf_tile == 128 || bf_tile == 256) return bf_tile;
+    return (Cout % 256 == 0) ? 256 : 128;
+}
+
+template <int TN_, bool BF>
+static int launch_wgrad_planes(const PlaneWgradGeom& g, hipStream_t st) {
+    constexpr int CH = BF ? 64 : 32;
+    constexpr size_t smem = 3ull * (TN_ / CH + 256 / CH) * 32 * PROW;
+    static_assert(smem <= 160 * 1024, "LDS");
+    auto kern = wgrad_planes_mfma<TN_, 256, BF>;
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
+    y4::note_kernel(BF ? "wgrad_planes_mfma<%d, 256, true>" : "wgrad_planes_mfma<%d, 256, false>", TN_);
+    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(512), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
 int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const unsigned* dy_amax, float* dw, void* workspace,
-                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st) {
+                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st, bool bf) {
     PlaneWgradGeom g{};
     g.x = static_cast<const unsigned char*>(x); g.dy = static_cast<const unsigned char*>(dy);
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.pad = (k - 1) / 2;
     const long long M = (long long)B * H * W;
     if (M >= (1ll << 31) - 65536) return Y4_ERR_SHAPE;     // (32-bit pixel counters in the kernel, with room for a K-step past M)
+    if (bf && ((Cin & 63) || (Cout & 63))) return Y4_ERR_SHAPE;
     g.M = (int)M; g.J = k * k * Cin;
-    planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split);
+    if ((unsigned long long)Cout * g.J * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+    const int tn = planes_wgrad_tn(Cout, bf);
+    planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split, tn);
     g.x_total_bytes = (unsigned long long)M * Cin * 4ull;
     g.dy_total_bytes = (unsigned long long)M * Cout * 4ull;
     // a block's 32-bit windows: its K range + the taps' reach
@@ -728,20 +893,23 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     } else {
         g.out = dw;
     }
-    constexpr size_t smem = 3ull * (128 / 32 + 256 / 32) * 32 * PROW;
-    auto kern = wgrad_planes_mfma<128, 256>;
-    static Y4DynLds lds_attr;                              // per device, see common.h
-    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
-    y4::note_kernel("wgrad_planes_mfma<128, 256>");
-    hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(512), smem, st, g);
-    Y4_CHECK_LAUNCH();
+    int rc;
+    if (!bf) rc = launch_wgrad_planes<128, false>(g, st);
+    else if (tn == 256) rc = launch_wgrad_planes<256, true>(g, st);
+    else rc = launch_wgrad_planes<128, true>(g, st);
+    if (rc != Y4_OK) return rc;
     if (g.splits > 1) return y4::slab_reduce(static_cast<const float*>(workspace), dw, (long long)Cout * g.J, g.splits, st);
     return Y4_OK;
 }
 
-int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st) {
+int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st, bool bf) {
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (bf) {
+        hipLaunchKernelGGL(planes_split_bf16_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C, static_cast<unsigned char*>(planes));
+        Y4_CHECK_LAUNCH();
+        return Y4_OK;
+    }
     hipLaunchKernelGGL(planes_split_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C, amax,
                        static_cast<unsigned char*>(planes));
     Y4_CHECK_LAUNCH();
@@ -751,13 +919,18 @@ int planes_split(const float* x, long long ld, long long M, int C, const unsigne
 }  // namespace y4
 
 // ======================================================================================== C ABI
+// conv mode 3: f16x2 planes (amax words required); conv mode 2: bf16 "planes" (amax words ignored, may be NULL)
+static inline bool pl_mode_ok() { const int m = y4_get_conv_mode(); return m == 3 || m == 2; }
+static inline bool pl_bf() { return y4_get_conv_mode() == 2; }
+
 extern "C" {
 
 int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, void* stream) {
-    if (!x || !amax || !planes) return Y4_ERR_NULL;
+    if (!x || !planes || (!amax && !pl_bf())) return Y4_ERR_NULL;
     if (M <= 0 || C <= 0 || (C & 31) || ldx < C || (ldx & 3)) return Y4_ERR_SHAPE;
+    if (pl_bf() && (C & 63)) return Y4_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return Y4_ERR_SHAPE;
-    return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream));
+    return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream), pl_bf());
 }
 
 int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,
@@ -765,9 +938,12 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
                              void* workspace, size_t workspace_bytes, void* dgrad_filter, size_t dgrad_filter_bytes,
                              void* stream) {
-    if (!x_planes || !w || !y || !x_amax || !workspace) return Y4_ERR_NULL;
+    if (!x_planes || !w || !y || !workspace) return Y4_ERR_NULL;
+    if (!pl_mode_ok()) return Y4_ERR_SHAPE;
+    const bool bf = pl_bf();
+    if (!bf && !x_amax) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cin, Cout, k, stride) || ldy < Cout || (ldy & 3)) return Y4_ERR_SHAPE;
-    if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
+    if (bf && (Cin & 63)) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_conv2d_fwd_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
         (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return Y4_ERR_SHAPE;
@@ -780,18 +956,20 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
     int rc;
     if (dgrad_filter) {
         // also the mirrored transposed planes for y4_conv2d_dgrad_planes_f32 (which then takes them with w == NULL): one launch
-        if (stride != 1 || (Cout & 31)) return Y4_ERR_SHAPE;
+        if ((Cout & 31) || (bf && (Cout & 63))) return Y4_ERR_SHAPE;
         if (dgrad_filter_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
         if (reinterpret_cast<uintptr_t>(dgrad_filter) & 15) return Y4_ERR_SHAPE;
         unsigned* hdr_t = reinterpret_cast<unsigned*>(static_cast<char*>(dgrad_filter) + (size_t)Cin * k * k * Cout * 6);
-        rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin, k * k,
-                                          Cout, true, st);
+        if (bf) rc = bf16_filter(w, planes, static_cast<unsigned short*>(dgrad_filter), Cout, Cin, k * k, true, st);
+        else rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin, k * k,
+                                               Cout, true, st);
     } else {
-        rc = y4::f16x2_filter_planes(w, planes, Cout, k * k * Cin, hdr, hdr + 16, st);
+        if (bf) rc = bf16_filter(w, planes, nullptr, Cout, Cin, k * k, false, st);
+        else rc = y4::f16x2_filter_planes(w, planes, Cout, k * k * Cin, hdr, hdr + 16, st);
     }
     if (rc != Y4_OK) return rc;
     int np = 0;
-    rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, nullptr, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st);
+    rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, nullptr, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st, bf);
     if (nparts_host) *nparts_host = np;
     return rc;
 }
@@ -802,10 +980,13 @@ int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx,
                                int B, int H, int W, int Cin, int Cout, int k,
                                void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                                const float* residual, int ldr, void* stream) {
-    if (!dy_planes || !dx || !dy_amax || !workspace) return Y4_ERR_NULL;     // w == NULL: workspace filled by the forward call
+    if (!dy_planes || !dx || !workspace) return Y4_ERR_NULL;     // w == NULL: workspace filled by the forward call
+    if (!pl_mode_ok()) return Y4_ERR_SHAPE;
+    const bool bf = pl_bf();
+    if (!bf && !dy_amax) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cout, Cin, k, 1) || lddx < Cin || (lddx & 3)) return Y4_ERR_SHAPE;
+    if (bf && (Cout & 63)) return Y4_ERR_SHAPE;
     if (residual && (ldr < Cin || (ldr & 3) || (reinterpret_cast<uintptr_t>(residual) & 15))) return Y4_ERR_SHAPE;
-    if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
     if ((reinterpret_cast<uintptr_t>(dy_planes) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
         (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(dx) & 15)) return Y4_ERR_SHAPE;
@@ -813,30 +994,39 @@ int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx,
     const long long total = (long long)Cin * k * k * Cout;
     unsigned* hdr = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)total * 6);
     if (w) {
-        const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout, hdr, hdr + 16, st, true);
+        const int rc = bf ? bf16_filter(w, nullptr, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, true, st)
+                          : y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, k * k, Cout, hdr, hdr + 16, st, true);
         if (rc != Y4_OK) return rc;
     }
-    return y4::planes_conv(dy_planes, dy_amax, workspace, hdr, dx, lddx, residual, ldr, nullptr, nullptr, B, H, W, Cout, Cin, k, 1, st);
+    return y4::planes_conv(dy_planes, dy_amax, workspace, hdr, dx, lddx, residual, ldr, nullptr, nullptr, B, H, W, Cout, Cin, k, 1, st, bf);
 }
 
 size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0) return 0;
     int ntn, ntj, splits, sps;
-    y4::planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps);
-    return (splits > 1 ? (size_t)splits * Cout * k * k * Cin * sizeof(float) : 0) + 64;
+    // the larger of the two modes' split counts (the mode may be switched between the size query and the call)
+    size_t most = 0;
+    for (int bf = 0; bf < 2; ++bf) {
+        y4::planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps, y4::planes_wgrad_tn(Cout, bf != 0));
+        const size_t need = splits > 1 ? (size_t)splits * Cout * k * k * Cin * sizeof(float) : 0;
+        if (need > most) most = need;
+    }
+    return most + 64;
 }
 
 int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, float* dw,
                                int B, int H, int W, int Cin, int Cout, int k,
                                void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
                                void* stream) {
-    if (!x_planes || !dy_planes || !dw || !x_amax || !dy_amax) return Y4_ERR_NULL;
+    if (!x_planes || !dy_planes || !dw) return Y4_ERR_NULL;
+    if (!pl_mode_ok()) return Y4_ERR_SHAPE;
+    const bool bf = pl_bf();
+    if (!bf && (!x_amax || !dy_amax)) return Y4_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31) || (k != 1 && k != 3)) return Y4_ERR_SHAPE;
-    if (y4_get_conv_mode() != 3) return Y4_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(dy_planes) & 15) ||
         (reinterpret_cast<uintptr_t>(dw) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k)) return Y4_ERR_WORKSPACE;
-    return y4::planes_wgrad(x_planes, x_amax, dy_planes, dy_amax, dw, workspace, workspace_bytes, B, H, W, Cin, Cout, k, y4_stream(stream));
+    return y4::planes_wgrad(x_planes, x_amax, dy_planes, dy_amax, dw, workspace, workspace_bytes, B, H, W, Cin, Cout, k, y4_stream(stream), bf);
 }
 
 }  // extern "C"

@@ -260,6 +260,15 @@ __device__ __forceinline__ void store_planes4(unsigned char* row_base, int c0, c
     }
 }
 
+// conv mode 2: four consecutive channels as bf16 (RN) into the first half of the pixel's fp32-sized row (conv_planes.hip, BF)
+__device__ __forceinline__ void store_bf16x4(unsigned char* row_base, int c0, const f32x4 o) {
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    us4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(unsigned short, (__bf16)o[e]);
+    *reinterpret_cast<us4*>(row_base + c0 * 2) = v;
+}
+
 // ---------------------------------------------------------------- BN apply + act (+ skip)
 __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -276,7 +285,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     unsigned amax = 0u;
     float ps = 1.f;
     const bool paired = (C & 7) == 0 && tpr >= 2;         // lanes 2k, 2k + 1: same pixel, adjacent channel quads, both in range
-    if (planes) {
+    // planes = 2: z (or twin) receives plain bf16 values, dense in the first half of each fp32-sized row (conv mode 2)
+    if (planes == 1) {
         const unsigned e8 = (*out_amax >> 23) & 0xffu;
         int se = 268 - (int)e8;                            // as f16x2_scale_exp (conv_f16x2.hip)
         if (e8 == 0u || e8 == 255u) se = 127;
@@ -313,7 +323,9 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
                 for (int e = 0; e < 4; ++e) o[e] = y4_act(v[u][e] * a[e] + b[e], act);
                 if (res) o += r[u];
                 if (planes) {
-                    store_planes4(reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : z + m * ldz), c0, o, ps, paired);
+                    unsigned char* row = reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : z + m * ldz);
+                    if (planes == 2) store_bf16x4(row, c0, o);
+                    else store_planes4(row, c0, o, ps, paired);
                     if (twin) st4(z + m * ldz + c0, o);
                 } else {
                     if (z) st4(z + m * ldz + c0, o);
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const double* __restrict__ acc, float* __restrict__ dy, long long lddy,
-    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds, int frozen) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds, int frozen, int bf) {
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     const double invM = frozen ? 0.0 : 1.0 / (double)M;    // frozen statistics: no batch-statistic terms in dy
@@ -503,7 +515,9 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
                     const float g = d[u][e] * y4_act_grad(ga[e] * xh + be[e], act);
                     o[e] = ga[e] * is[e] * (g - k1[e] - xh * k2[e]);
                 }
-                if (bounds) {
+                if (bf) {
+                    store_bf16x4(reinterpret_cast<unsigned char*>(dy + m * lddy), c0, o);      // conv mode 2: plain bf16, no scale
+                } else if (bounds) {
                     store_planes4(reinterpret_cast<unsigned char*>(dy + m * lddy), c0, o, ps, paired);
                 } else {
                     st4(dy + m * lddy + c0, o);
@@ -512,7 +526,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
             }
         }
     }
-    if (out_amax && !bounds) amax_commit(amax, out_amax);
+    if (out_amax && !bounds && !bf) amax_commit(amax, out_amax);
 }
 
 // generic column sums (C arbitrary, scalar loads): dbias of the 255-channel head convs.  Two fixed-order stages, no atomics:
@@ -875,8 +889,9 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
                       void* stream) {
     if (!y || !mean || !invstd || !gamma || !beta) return Y4_ERR_NULL;
     if (!z && (!out_amax || z_planes)) return Y4_ERR_NULL;                       // measure-only needs the word to fill
+    if (z_planes < 0 || z_planes > 3) return Y4_ERR_SHAPE;
     if (planes_twin && (!z_planes || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
-    if (z_planes && (!out_amax || (!planes_twin && ldz != C) || (C & 31))) return Y4_ERR_SHAPE;   // planes: dense rows, whole K tiles
+    if (z_planes && ((!out_amax && z_planes != 3) || (!planes_twin && ldz != C) || (C & 31))) return Y4_ERR_SHAPE;   // planes: dense rows, whole K tiles
     if (z_planes == 2) {
         // the scale comes from an analytic bound of max|z| (no measuring pass); a residual must bring its own maximum
         if (residual && !res_amax) return Y4_ERR_NULL;
@@ -891,7 +906,7 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
                        (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
-                       M, C, rm.tpr, rm.rpb, out_amax, z_planes ? 1 : 0, planes_twin);
+                       M, C, rm.tpr, rm.rpb, z_planes == 3 ? nullptr : out_amax, z_planes == 3 ? 2 : (z_planes ? 1 : 0), planes_twin);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -900,9 +915,11 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            int act, float* dy, int lddy, float* dgamma, float* dbeta,
                            long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                           unsigned* f16_planes, int frozen, void* stream) {
+                           unsigned* f16_planes, int flags, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
+    const int frozen = flags & 1, bf = (flags >> 1) & 1;
     if (frozen && f16_planes) return Y4_ERR_SHAPE;         // (the plane bound is derived for batch statistics)
+    if (bf && (f16_planes || lddy != C || (C & 31))) return Y4_ERR_SHAPE;
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
@@ -928,7 +945,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
                        (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,
-                       out_amax, f16_planes, frozen ? 1 : 0);
+                       out_amax, f16_planes, frozen ? 1 : 0, bf);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

@@ -124,7 +124,10 @@ def takes_planes(m):
     ci, co = m.conv.in_channels, m.conv.out_channels
     if ci % 32 or co % 32 or co < 128 or ci < 64 or m.kernel_size not in (1, 3):
         return False
-    return ops.PLANES['on'] and ops.f16x2_mode() and m.conv.weight.is_cuda
+    if not (ops.PLANES['on'] and m.conv.weight.is_cuda):
+        return False
+    pm = ops.planes_mode()
+    return pm == 'f16x2' or (pm == 'bf16' and ci % 64 == 0 and co % 64 == 0)     # bf16 rows hold 64 channels
 
 
 def chain(seq, x, last=False):

@@ -112,6 +112,14 @@ def f16x2_mode():
     return lib().y4_get_conv_mode() == 3
 
 
+def planes_mode():
+    """Which form pre-split operands take in the current conv mode: 'f16x2' (mode 3: two fp16 pieces per element under a
+    per-tensor scale), 'bf16' (mode 2, BASELINE configs[4]: plain bf16 values in the first half of each fp32-sized pixel row),
+    None (the other modes have no DMA-fed kernels)."""
+    m = lib().y4_get_conv_mode()
+    return 'f16x2' if m == 3 else ('bf16' if m == 2 else None)
+
+
 def new_amax(device, n=1):
     """n (1 or 8) zeroed device words out of a ring of 8192; each half is re-zeroed (one tiny fill) when the ring enters
     it, i.e. >= 4096 words (several training steps) after its cells were handed out.  Every cell carries the generation
@@ -375,10 +383,13 @@ def planes_split_raw(x, amax=None):
     L = lib()
     B, C, H, W = x.shape
     x, ldx = as_nhwc(x)
-    if amax is None:
-        amax = amax_of(x)
-    if amax is None:
-        amax = amax_raw(x)
+    if planes_mode() == 'bf16':
+        amax = None                                  # plain bf16 values: no scale
+    else:
+        if amax is None:
+            amax = amax_of(x)
+        if amax is None:
+            amax = amax_raw(x)
     buf = torch.empty((B, H, W, C * 4), dtype=torch.uint8, device=x.device)
     check(L.y4_planes_split_f32(_ptr(x), ldx, B * H * W, C, _ptr(amax), _ptr(buf), _stream()), 'planes_split')
     return Planes(buf, (B, C, H, W), amax)
@@ -424,7 +435,7 @@ def planes_of(t):
     """Planes view of a tensor written pre-split by bn_act_fwd_raw / bn_act_bwd_raw (tag y4_planes); None otherwise."""
     if t is None or not getattr(t, 'y4_planes', False):
         return None
-    return Planes(t, t.shape, t.y4_amax)
+    return Planes(t, t.shape, getattr(t, 'y4_amax', None))
 
 
 def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None, prepared=None):
@@ -591,11 +602,19 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
     if residual is not None:
         residual, ldr = as_nhwc(residual)
     if planes:
-        cell = planes_cell(y.device)
         both = planes == 'both'
         zp = empty_nhwc(B, C, H, W, y.device)        # the pre-split tensor (float32-typed, 4 bytes per element)
         z = (out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)) if both else zp
         args = (_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act], _ptr(residual), ldr)
+        if planes_mode() == 'bf16':                  # conv mode 2: plain bf16 values in the first half of each row, no scale
+            check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, None, 3, None,
+                                      _ptr(zp) if both else None, _stream()), 'bn_act_fwd(bf16)')
+            zp = as_planes(zp)
+            if both:
+                z.y4_twin = zp
+                return z
+            return zp
+        cell = planes_cell(y.device)
         res_cell = amax_of(residual) if residual is not None else None
         if residual is not None and res_cell is None:
             check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), 0, None, None, _stream()), 'bn_act_fwd(measure)')
@@ -617,7 +636,7 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
 
 
 def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None,
-                   frozen=False):
+                   frozen=False, bf16=False):
     """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
     L = lib()
     B, C, H, W = y.shape
@@ -633,7 +652,8 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
-                              _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), 1 if frozen else 0, _stream()), 'bn_act_bwd')
+                              _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), (1 if frozen else 0) | (2 if bf16 else 0), _stream()),
+          'bn_act_bwd')
     return dy, dgamma, dbeta
 
 
@@ -757,13 +777,14 @@ class ConvBNActFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         # conv mode 3: operand maxima travel with the tensors (see "operand maxima" above)
         f16 = f16x2_mode() and x.shape[1] != 3
+        bfm = planes_mode() == 'bf16'                # conv mode 2: plane layers run the DMA kernels on bf16 operands
         # pre-split operands (conv_planes.hip): x arrives as planes when its producer was asked to (out_planes, below);
         # all three of this layer's convs then run on the DMA kernels, dy leaving the BatchNorm backward as planes too
         xp = planes_of(x)
         if xp is None and cfg.get('x_twin') is not None:
             xp = planes_of(cfg['x_twin'])            # x itself is fp32 (it has other consumers); its pre-split twin feeds this conv
         ctx.x_planes = xp is not None
-        if xp is not None and not (f16 and bn and training and s == 1 and weight.shape[0] % 32 == 0 and x.shape[1] % 32 == 0):
+        if xp is not None and not ((f16 or bfm) and bn and training and s == 1 and weight.shape[0] % 32 == 0 and x.shape[1] % 32 == 0):
             raise Y4Error('a pre-split (planes) tensor reached a conv that cannot consume it')
         x_amax = live(cfg.get('x_amax')) if f16 else None
         z_amax = None
@@ -778,7 +799,7 @@ class ConvBNActFn(torch.autograd.Function):
                 raise ValueError('Expected more than 1 value per channel when training')   # as nn.BatchNorm2d
             # the backward pass wants the transposed planes of the same filter: the forward split launch writes both
             ctx.dgrad_filter = None
-            if (f16 and ctx.needs_input_grad[0] and x.shape[1] % 32 == 0 and fast_conv_shape(x.shape[1], k, s)
+            if ((f16 or (bfm and xp is not None)) and ctx.needs_input_grad[0] and x.shape[1] % 32 == 0 and fast_conv_shape(x.shape[1], k, s)
                     and weight.shape[0] % 4 == 0 and (xp is None or weight.shape[0] % 32 == 0)):
                 ctx.dgrad_filter = dgrad_filter_buffer(x.shape[1], weight.shape[0], k, x.device)
             if xp is not None:
@@ -789,10 +810,10 @@ class ConvBNActFn(torch.autograd.Function):
                                                        cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax,
                                                        dgrad_filter=ctx.dgrad_filter)
             want = cfg.get('out_planes')
-            if want and f16 and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
+            if want and (f16 or bfm) and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
                 z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest if want == 'both' else None,
                                    planes='both' if want == 'both' else True)
-                z_amax = z.y4_amax
+                z_amax = getattr(z, 'y4_amax', None)
                 if io is not None:
                     io['z_planes'] = want != 'both'
                     io['z_twin'] = getattr(z, 'y4_twin', None)
@@ -867,12 +888,13 @@ class ConvBNActFn(torch.autograd.Function):
                     and ctx.needs_input_grad[3] and ctx.needs_input_grad[4])
             # a layer whose input came pre-split runs dgrad and wgrad on the plane kernels: dy leaves the BatchNorm
             # backward sweep already split, scaled by a bound of max|dy| the reduce pass derives (word [5] of the cell)
-            planes = planes_cell(dz.device, 8) if x_planes else None
+            bfp = x_planes and planes_mode() == 'bf16'       # conv mode 2: dy leaves as plain bf16, no scale word
+            planes = planes_cell(dz.device, 8) if (x_planes and not bfp) else None
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
             dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                                gp.grad if sink else None, bp.grad if sink else None,
                                                out_amax=None if planes is not None else dy_amax, planes=planes,
-                                               frozen=ctx.mode == 'bn_eval_grad')
+                                               frozen=ctx.mode == 'bn_eval_grad', bf16=bfp)
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
                 gp._y4_grad_fresh = bp._y4_grad_fresh = False
@@ -966,7 +988,8 @@ def fork(x):
     if twin is not None:
         a.y4_twin = b.y4_twin = twin
     if getattr(x, 'y4_planes', False):               # a pre-split tensor read by two plane-taking convs (CSP split convs)
-        return as_planes(a, x.y4_amax), as_planes(b, x.y4_amax)
+        cell = getattr(x, 'y4_amax', None)
+        return as_planes(a, cell), as_planes(b, cell)
     return tag_amax(a, cell), tag_amax(b, cell)
 
 
