@@ -246,10 +246,12 @@ def bf16_mode(dev):
 def test_bf16_planes_forward_dgrad_wgrad_are_exact_bf16_products(dev, bf16_mode, case, tile, monkeypatch):
     """BASELINE configs[4] (bf16 MFMA conv): operands rounded to bf16 (RN) by the producers, products exact in fp32, fp32
     accumulation -> against torch fp64 on the SAME bf16-rounded operands the only difference is the accumulation order:
-    2e-6 of the range, forward / dgrad / wgrad, every tile shape the dispatcher may choose (Y4_BF_TILE is read once per
-    process, so the three values are three parametrisations of the first call only; the default run covers the heuristic)."""
+    2e-6 of the range, forward / dgrad / wgrad, every tile shape the dispatcher may choose (Y4_BF_TILE / Y4_BF_WGRAD_TILE, read
+    on every call: 0 = the dispatcher's own choice, 1 = 256 x 128 / 128-row wgrad tiles, 2 = 256 x 256 / 256-row)."""
     from yolov4_amd import ops
     B, ci, co, k, s, H, W = case
+    monkeypatch.setenv('Y4_BF_TILE', tile)
+    monkeypatch.setenv('Y4_BF_WGRAD_TILE', {'0': '0', '1': '128', '2': '256'}[tile])
     x = recipe.randn((B, ci, H, W), 7)
     w = recipe.randn((co, ci, k, k), 8, 1.0 / np.sqrt(ci * k * k))
     ref = F.conv2d(_bf(x), _bf(w), None, s, (k - 1) // 2)
@@ -311,13 +313,25 @@ def test_bf16_chain_and_resblock_through_planes_match_the_register_staged_bf16_p
         (out * w).sum().backward()
         torch.cuda.synchronize()
         return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(seq.parameters()) + list(rb.parameters())]
+    import yolov4_amd
     was = ops.PLANES['on']
     try:
         o1, gx1, gp1 = run(True)
         o0, gx0, gp0 = run(False)
+        yolov4_amd.set_conv_mode('f16x2')            # the fp32-grade evaluation of the same graph: the yardstick
+        ot, gxt, gpt = run(False)
     finally:
         ops.PLANES['on'] = was
-    assert float((o1 - o0).abs().max()) <= 2e-4 * float(o0.abs().max())
-    assert float((gx1 - gx0).abs().max()) <= 2e-3 * float(gx0.abs().max())
-    for a, b in zip(gp1, gp0):
-        assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-6)
+        yolov4_amd.set_conv_mode('bf16')
+    # The two bf16 arms are not bit-equal: their fp32 pre-rounding values differ in the last bits (accumulation order), which
+    # now and then flips a bf16 rounding (one bf16 ulp = 4e-3 of the element), and BatchNorm backward amplifies that.  What
+    # must hold: each arm is an equally good bf16 evaluation of the graph -- the distance of the plane arm from the fp32-grade
+    # result is that of the register-staged arm (within 25 %), and the two arms are closer to each other than to the truth.
+    def close(a, b, t, what):
+        top = max(float(t.abs().max()), 1e-6)
+        e_on, e_off, d = float((a - t).abs().mean()) / top, float((b - t).abs().mean()) / top, float((a - b).abs().mean()) / top
+        assert e_on <= 1.25 * e_off + 1e-6 and d <= e_off + 1e-6 and e_off < 5e-2, (what, e_on, e_off, d)
+    close(o1, o0, ot, 'out')
+    close(gx1, gx0, gxt, 'dx')
+    for i, (a, b, t) in enumerate(zip(gp1, gp0, gpt)):
+        close(a, b, t, f'param {i}')

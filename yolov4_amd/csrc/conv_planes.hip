@@ -650,7 +650,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
                 for (int j = 0; j < TN; ++j) {
                     const int jj = j0 + wj * WTJ + j * 16 + frb;
                     const unsigned off = (n < g.Cout && jj < g.J) ? ((unsigned)n * (unsigned)g.J + (unsigned)jj) * 4u : 0xffffffffu;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc0[i][j][e]), ors, (int)off, 0, 0);
+                    const float v = acc0[i][j][e];         // (a bit_cast straight on the vector-element lvalue reads element 0)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ors, (int)off, 0, 0);
                 }
             }
         return;
@@ -810,7 +811,8 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
     const bool small = small_mode == 2 || (small_mode == 1 && g.K <= 256);
     if (bf) {
         // 256 x 256 (wave tile 128 x 64) unless its grid quantises badly on 256 CUs or N fits one 128-column tile
-        static const int bf_tile = getenv("Y4_BF_TILE") ? atoi(getenv("Y4_BF_TILE")) : 0;     // 1: 256x128 always, 2: 256x256 always
+        const char* bt = getenv("Y4_BF_TILE");             // experiments / tests: 1: 256x128 always, 2: 256x256 always
+        const int bf_tile = bt ? atoi(bt) : 0;
         const long long mt = (g.M + 255) / 256;
         const long long r256 = (mt * ((N + 255) / 256) + 255) / 256, r128 = (mt * ((N + 127) / 128) + 255) / 256;
         const bool big = bf_tile == 2 || (bf_tile == 0 && N > 128 && (double)r256 * 2.0 <= (double)r128 * 1.25);
@@ -848,9 +850,10 @@ void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, 
 
 // bf16 form: 256-row n tiles (wave tile 128 x 64) when Cout fills them
 int planes_wgrad_tn(int Cout, bool bf) {
-    static const int bf_tile = getenv("Y4_BF_WGRAD_TILE") ? atoi(getenv("Y4_BF_WGRAD_TILE")) : 0;     // 128 / 256: forced
     if (!bf) return 128;
-    if (bf_tile == 128 || bf_tile == 256) return bf_tile;
+    const char* bt = getenv("Y4_BF_WGRAD_TILE");           // experiments / tests: 128 / 256 forced
+    const int bf_tile = bt ? atoi(bt) : 0;
+    if (bf_tile == 128 || (bf_tile == 256 && Cout >= 256)) return bf_tile;
     return (Cout % 256 == 0) ? 256 : 128;
 }
 
