@@ -252,7 +252,7 @@ def gather_symbol(transposed, M, N, Cs, Cs_valid, k, stride, ld):
     Cs = channels of the gathered tensor (padded), ld = its pixel pitch."""
     mode = args_conv_mode()
     if Cs == 3:
-        return 'conv_stem_fwd_bf16x3_kernel' if mode in ('bf16x3', 'f16x2') else 'conv_stem_fwd_kernel'
+        return 'conv_stem_fwd_bf16x3_kernel' if mode in ('bf16x3', 'f16x2', 'bf16') else 'conv_stem_fwd_kernel'
     tr = 'true' if transposed else 'false'
     if mode == 'f16x2':
         ms = int(os.environ.get('Y4_F16X2_SHAPE', '16'))

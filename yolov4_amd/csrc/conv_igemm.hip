@@ -2072,7 +2072,7 @@ int y4_conv2d_stem_fwd_f32(const float* x, long long sxb, long long sxc, long lo
     const long long blocks = (g.M + 255) / 256;
     if (blocks >= (1ll << 31)) return Y4_ERR_SHAPE;
     // matrix-core variant: bf16x3 arithmetic, 32-bit byte offsets into x (non-negative strides)
-    const bool mfma_ok = (g_conv_mode == 1 || g_conv_mode == 3) && sxb >= 0 && sxc >= 0 && sxh >= 0 && sxw >= 0 &&
+    const bool mfma_ok = (g_conv_mode >= 1 && g_conv_mode <= 3) && sxb >= 0 && sxc >= 0 && sxh >= 0 && sxw >= 0 &&
                          ((long long)(B - 1) * sxb + 2 * sxc + (long long)(H - 1) * sxh + (long long)(W - 1) * sxw + 1) * 4 < 0xfffffff0ll &&
                          (long long)H * W < (1 << 24);
     if (mfma_ok) {
