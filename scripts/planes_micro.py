@@ -36,7 +36,31 @@ def main():
         xa = ops.amax_raw(x)
         xp = ops.planes_split_raw(x, xa)
         Ho0 = (H + 2 * ((k - 1) // 2) - k) // s + 1
-        if MODE == 'fwd':
+        if MODE in ('fwd_agpr', 'dgrad_agpr'):
+            # experiment (experiments/agpr_conv/README.md; needs that kernel compiled into the library): 'regstage' column = the
+            # product plane kernel, 'planes' column = the AGPR-accumulator variant
+            def with_env(val, f):
+                def run():
+                    os.environ['Y4_PLANES_AGPR'] = val
+                    try:
+                        return f()
+                    finally:
+                        os.environ['Y4_PLANES_AGPR'] = '0'
+                return run
+            if MODE == 'fwd_agpr':
+                f = lambda: ops.conv_fwd_planes_raw(xp, w, k, s)
+            else:
+                if s != 1:
+                    continue
+                dy = torch.randn(B, co, Ho0, Ho0, device=dev).contiguous(memory_format=torch.channels_last)
+                dyp = ops.planes_split_raw(dy, ops.amax_raw(dy))
+                f = lambda: ops.conv_dgrad_planes_raw(dyp, w, (B, ci, H, H), k)
+            arms = {'regstage': with_env('0', f), 'planes': with_env('1', f)}
+            ya = arms['regstage'](); yb = arms['planes']()
+            ya = ya[0] if isinstance(ya, tuple) else ya; yb = yb[0] if isinstance(yb, tuple) else yb
+            torch.cuda.synchronize()
+            print('max |agpr - product| / max:', float((ya - yb).abs().max() / ya.abs().max()), ops.last_conv_kernel(), flush=True)
+        elif MODE == 'fwd':
             arms = {'regstage': lambda: ops.conv_fwd_bnstats_raw(x, w, k, s, None, None, None, 0.1, 1e-5, x_amax=xa),
                     'planes': lambda: ops.conv_fwd_planes_raw(xp, w, k, s)}
         else:
