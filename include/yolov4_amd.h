@@ -143,21 +143,24 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
                              int B, int H, int W, int Cin, int Cout, int k, int stride,
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
                              void* workspace, size_t workspace_bytes,
-                             void* dgrad_filter /* nullable, stride 1: as in y4_conv2d_fwd_bnstats_f32, for y4_conv2d_dgrad_planes_f32 */,
+                             void* dgrad_filter /* nullable: as in y4_conv2d_fwd_bnstats_f32 -- stride 1: for
+                                y4_conv2d_dgrad_planes_f32 (mirrored taps); stride 2: for y4_conv2d_dgrad_f32 (the register-staged
+                                parity-class dgrad, taps as they are) */,
                              size_t dgrad_filter_bytes, void* stream);
 
-/* dgrad / wgrad of a STRIDE-1 conv over planes (dy, and for wgrad also x, pre-split as above; Cin % 32 == 0, Cout % 32 == 0):
- * the same arithmetic as y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 in conv mode 3.  dgrad runs the forward DMA kernel on the
+/* dgrad (stride 1) / wgrad (stride 1, and the 3x3 stride-2 layers on even maps) of a conv over planes (dy, and for wgrad also
+ * x, pre-split as above; Cin % 32 == 0, Cout % 32 == 0): the same arithmetic as y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 in
+ * conv mode 3 (conv mode 2: plain bf16 operands, 64-channel multiples, stride 1).  dgrad runs the forward DMA kernel on the
  * mirrored transposed filter (workspace: y4_conv2d_dgrad_workspace()); wgrad stages both operands pixel-major and takes its
  * fragments through the hardware transpose read (split-K slabs in y4_conv2d_wgrad_planes_workspace() bytes, fixed-order
- * reduce: deterministic).  Autograd of the same nn.Conv2d, darknet/darknet.py:31-36. */
+ * reduce: deterministic); H, W are the INPUT dims.  Autograd of the same nn.Conv2d, darknet/darknet.py:31-36. */
 int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w /* NULL: workspace prepared by the forward call */, float* dx, int lddx,
                                int B, int H, int W, int Cin, int Cout, int k,
                                void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                                const float* residual, int ldr, void* stream);
-size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k);
+size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride);
 int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, float* dw,
-                               int B, int H, int W, int Cin, int Cout, int k,
+                               int B, int H, int W, int Cin, int Cout, int k, int stride,
                                void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
                                void* stream);
 
@@ -261,6 +264,9 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                          plane conv kernels (layout as y4_bn_act_fwd_f32 z_planes; lddy == C, C % 32 == 0), scaled by a
                          bound of max|dy| derived before the sweep; word [5] receives that bound and serves as dy_amax
                          of y4_conv2d_dgrad_planes_f32 / y4_conv2d_wgrad_planes_f32 */,
+                      float* planes_twin /* nullable, with f16_planes: dy stays fp32 (pitch lddy) and planes_twin [M][C]
+                         receives the pre-split copy -- a layer whose wgrad runs on the plane kernel and whose dgrad does
+                         not (3x3 stride 2) */,
                       int frozen_stats /* bit 0: mean / invstd are constants (eval-mode BatchNorm under autograd: running
                          statistics), so dy = gamma invstd g without the two batch-statistic terms; dgamma / dbeta as usual.
                          bit 1 (conv mode 2): dy leaves as plain bf16 in the first half of each fp32-sized row, as

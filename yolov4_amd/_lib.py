@@ -42,8 +42,8 @@ PROTOTYPES = {
     'y4_planes_split_f32': (I, [P, I, L, I, P, P, P]),
     'y4_conv2d_fwd_planes_f32': (I, [P, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P, Z, P, Z, P]),
     'y4_conv2d_dgrad_planes_f32': (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P, P, I, P]),
-    'y4_conv2d_wgrad_planes_workspace': (Z, [I, I, I, I, I, I]),
-    'y4_conv2d_wgrad_planes_f32': (I, [P, P, P, I, I, I, I, I, I, P, Z, P, P, P]),
+    'y4_conv2d_wgrad_planes_workspace': (Z, [I, I, I, I, I, I, I]),
+    'y4_conv2d_wgrad_planes_f32': (I, [P, P, P, I, I, I, I, I, I, I, P, Z, P, P, P]),
     'y4_conv2d_generic_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P]),
     'y4_conv2d_generic_dgrad_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, I, P]),
     'y4_conv2d_generic_wgrad_f32': (I, [P, I, P, I, P, I, I, I, I, I, I, I, P]),
@@ -60,7 +60,7 @@ PROTOTYPES = {
     'y4_bn_finalize_partials_f32': (I, [P, L, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_stats_f32': (I, [P, I, L, I, P, P, P, P, P, F, F, P, Z, P]),
     'y4_bn_act_fwd_f32': (I, [P, I, P, P, P, P, I, P, I, P, I, L, I, P, I, P, P, P]),
-    'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, I, P]),
+    'y4_bn_act_bwd_f32': (I, [P, I, P, I, P, P, P, P, I, P, I, P, P, L, I, P, Z, P, P, P, I, P]),
     'y4_bias_grad_workspace': (Z, [L, I]),
     'y4_bias_grad_f32': (I, [P, I, L, I, P, P, Z, P]),
     'y4_bn_fold_f32': (I, [P, P, P, P, F, P, P, I, P]),

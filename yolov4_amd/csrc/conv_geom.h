@@ -83,7 +83,8 @@ int planes_split(const float* x, long long ld, long long M, int C, const unsigne
 void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn = 128);
 int planes_wgrad_tn(int Cout, bool bf);
 int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const unsigned* dy_amax, float* dw, void* workspace,
-                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st, bool bf = false);
+                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st, bool bf = false,
+                 int stride = 1);
 
 // Name of the conv kernel launched last on this host thread, spelled as rocprofv3 prints the symbol (bench.py names the
 // dominant kernel with it instead of restating the dispatch rules).

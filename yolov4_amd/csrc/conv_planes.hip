@@ -399,7 +399,7 @@ struct PlaneWgradGeom {
     const unsigned char* x;            // planes [B][H][W][Cin / 32][128 B]
     const unsigned char* dy;           // planes [B][H][W][Cout / 32][128 B]
     float* out;                        // [splits][Cout][J] slabs, or dW itself when splits == 1
-    int B, H, W, Cin, Cout, k, pad, M, J;
+    int B, H, W, Cin, Cout, k, pad, M, J;   // H, W, M: the dy grid (= the x grid at stride 1; at stride 2 x is 2H x 2W)
     int ntn, ntj, splits, steps_per_split;
     unsigned long long x_total_bytes, dy_total_bytes;
     const unsigned* x_amax; const unsigned* dy_amax;
@@ -430,7 +430,9 @@ template <int N> __device__ __forceinline__ void pl_wait_vm() {      // counted 
 // four 16-channel tiles of ONE plane (f16x2: [hi 0-15 | hi 16-31 | lo 0-15 | lo 16-31]), one bf16 MFMA per tile pair and
 // K-step into one accumulator set; <128, 256>: 24 KB per K-step, <256, 256> (wave tile 128 x 64): 32 KB per K-step, the f16x2
 // kernel's bytes per MFMA cycle.  The result leaves through raw buffer stores (the LDS patches of the f16x2 form do not fit).
-template <int TN_, int TJ_, bool BF>
+// SD = 2: the 3x3 stride-2 layers (H, W of the input even): dy pixel p = (b, h, w) reads x pixel (b, 2h + r - 1, 2w + q - 1),
+// whose raster index is 4 p - 2 w + (r - 1) 2W + (q - 1) -- still one multiply-add per lane and K-step from the running (p, w).
+template <int TN_, int TJ_, bool BF, int SD = 1>
 __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom g) {
     constexpr int NWAVE = 8, WN2 = 2, WJ = 4;
     constexpr int BAR = 2;                                 // row tile in front of whose MFMAs the barrier sits (see `step`)
@@ -463,8 +465,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
 
     // ---- 32-bit windows: dy from pixel P0; x from pixel P0 - (pad W + pad) (the earliest pixel a tap can reach), >= 0
     const unsigned pitch_x = (unsigned)g.Cin * 4u, pitch_dy = (unsigned)g.Cout * 4u;
-    const long long back = (long long)g.pad * g.W + g.pad;
-    const long long Pw = P0 > back ? P0 - back : 0;
+    const long long back = SD == 1 ? (long long)g.pad * g.W + g.pad : 2ll * g.W + 2ll * g.W + 1;     // S = 2: 2 w <= 2 W, one x row (2 W) + 1
+    const long long Pw = SD * SD * P0 > back ? SD * SD * P0 - back : 0;     // first x pixel of the window (x raster)
     const unsigned long long dy_skip = (unsigned long long)P0 * pitch_dy, x_skip = (unsigned long long)Pw * pitch_x;
     const unsigned long long dy_left = g.dy_total_bytes > dy_skip ? g.dy_total_bytes - dy_skip : 0ull;
     const unsigned long long x_left = g.x_total_bytes > x_skip ? g.x_total_bytes - x_skip : 0ull;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
             const int c32 = jg - tap * CC;
             const int r = tap / g.k, q = tap - r * g.k;
             x_pk |= (unsigned)((ok ? r - g.pad + 2 : 15) | ((q - g.pad + 2) << 4)) << (8 * i);
-            x_const[i] = (unsigned)((long long)(P0 - Pw) * pitch_x) + (unsigned)(((r - g.pad) * g.W + (q - g.pad)) * (int)pitch_x) +
+            x_const[i] = (unsigned)((long long)(SD * SD * P0 - Pw) * pitch_x) + (unsigned)(((r - g.pad) * (SD * g.W) + (q - g.pad)) * (int)pitch_x) +
                          (unsigned)c32 * 128u + srcoff;
         }
     }
@@ -525,8 +527,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
             } else {
                 const int i = p - PA;
                 const int dh = (int)((x_pk >> (8 * i)) & 15u) - 2, dw = (int)((x_pk >> (8 * i + 4)) & 15u) - 2;
-                const bool ok = lp < g.M && (unsigned)(lh + dh) < (unsigned)g.H && (unsigned)(lw + dw) < (unsigned)g.W;
-                const unsigned vo = ok ? lbase + x_const[i] : OOB;
+                const bool ok = lp < g.M && (unsigned)(SD * lh + dh) < (unsigned)(SD * g.H) && (unsigned)(SD * lw + dw) < (unsigned)(SD * g.W);
+                const unsigned lb = SD == 1 ? lbase : (unsigned)(4 * (lp - (int)P0) - 2 * lw) * pitch_x;     // (x pixel - S^2 P0) * pitch
+                const unsigned vo = ok ? lb + x_const[i] : OOB;
                 const int b = ((wave >> 2) * PB + i) * 4 + (wave & 3);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_ptr)(st + A_BYTES + b * 1024), 16, (int)vo, 0, 0, 0);
             }
@@ -857,24 +860,29 @@ int planes_wgrad_tn(int Cout, bool bf) {
     return (Cout % 256 == 0) ? 256 : 128;
 }
 
-template <int TN_, bool BF>
+template <int TN_, bool BF, int S = 1>
 static int launch_wgrad_planes(const PlaneWgradGeom& g, hipStream_t st) {
     constexpr int CH = BF ? 64 : 32;
     constexpr size_t smem = 3ull * (TN_ / CH + 256 / CH) * 32 * PROW;
     static_assert(smem <= 160 * 1024, "LDS");
-    auto kern = wgrad_planes_mfma<TN_, 256, BF>;
+    auto kern = wgrad_planes_mfma<TN_, 256, BF, S>;
     static Y4DynLds lds_attr;                              // per device, see common.h
     if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
-    y4::note_kernel(BF ? "wgrad_planes_mfma<%d, 256, true>" : "wgrad_planes_mfma<%d, 256, false>", TN_);
+    y4::note_kernel(BF ? "wgrad_planes_mfma<%d, 256, true, %d>" : "wgrad_planes_mfma<%d, 256, false, %d>", TN_, S);
     hipLaunchKernelGGL(kern, dim3(g.ntn * g.ntj * g.splits), dim3(512), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
 
+// H, W: the INPUT (x) grid; stride 2 (k = 3, H and W even): dy lives on H/2 x W/2
 int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const unsigned* dy_amax, float* dw, void* workspace,
-                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st, bool bf) {
+                 size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st, bool bf, int stride) {
     PlaneWgradGeom g{};
     g.x = static_cast<const unsigned char*>(x); g.dy = static_cast<const unsigned char*>(dy);
+    if (stride == 2) {
+        if (k != 3 || (H & 1) || (W & 1) || bf) return Y4_ERR_SHAPE;
+        H /= 2; W /= 2;                                    // from here on: the dy grid
+    } else if (stride != 1) return Y4_ERR_SHAPE;
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.pad = (k - 1) / 2;
     const long long M = (long long)B * H * W;
     if (M >= (1ll << 31) - 65536) return Y4_ERR_SHAPE;     // (32-bit pixel counters in the kernel, with room for a K-step past M)
@@ -883,11 +891,12 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     if ((unsigned long long)Cout * g.J * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
     const int tn = planes_wgrad_tn(Cout, bf);
     planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split, tn);
-    g.x_total_bytes = (unsigned long long)M * Cin * 4ull;
+    g.x_total_bytes = (unsigned long long)M * stride * stride * Cin * 4ull;
     g.dy_total_bytes = (unsigned long long)M * Cout * 4ull;
-    // a block's 32-bit windows: its K range + the taps' reach
+    // a block's 32-bit windows: its K range + the taps' reach (x pixels: stride^2 per dy pixel)
     const unsigned long long range_px = (unsigned long long)g.steps_per_split * 32ull + 2ull * (unsigned long long)(g.pad * W + g.pad) + 64ull;
-    if (range_px * (unsigned long long)(Cin > Cout ? Cin : Cout) * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+    const unsigned long long range_x = stride == 1 ? range_px : 4ull * range_px + 8ull * (unsigned long long)W + 64ull;
+    if (range_px * (unsigned long long)Cout * 4ull >= 0xfffffff0ull || range_x * (unsigned long long)Cin * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
     g.x_amax = x_amax; g.dy_amax = dy_amax;
     const size_t slab = (size_t)Cout * g.J * sizeof(float);
     if (g.splits > 1) {
@@ -897,7 +906,7 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
         g.out = dw;
     }
     int rc;
-    if (!bf) rc = launch_wgrad_planes<128, false>(g, st);
+    if (!bf) rc = stride == 2 ? launch_wgrad_planes<128, false, 2>(g, st) : launch_wgrad_planes<128, false>(g, st);
     else if (tn == 256) rc = launch_wgrad_planes<256, true>(g, st);
     else rc = launch_wgrad_planes<128, true>(g, st);
     if (rc != Y4_OK) return rc;
@@ -963,9 +972,11 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
         if (dgrad_filter_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
         if (reinterpret_cast<uintptr_t>(dgrad_filter) & 15) return Y4_ERR_SHAPE;
         unsigned* hdr_t = reinterpret_cast<unsigned*>(static_cast<char*>(dgrad_filter) + (size_t)Cin * k * k * Cout * 6);
+        // stride 1: mirrored (the plane dgrad is the forward kernel); stride 2: as the register-staged dgrad wants them
+        if (bf && stride != 1) return Y4_ERR_SHAPE;
         if (bf) rc = bf16_filter(w, planes, static_cast<unsigned short*>(dgrad_filter), Cout, Cin, k * k, true, st);
         else rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin, k * k,
-                                               Cout, true, st);
+                                               Cout, stride == 1, st);
     } else {
         if (bf) rc = bf16_filter(w, planes, nullptr, Cout, Cin, k * k, false, st);
         else rc = y4::f16x2_filter_planes(w, planes, Cout, k * k * Cin, hdr, hdr + 16, st);
@@ -1004,8 +1015,9 @@ int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx,
     return y4::planes_conv(dy_planes, dy_amax, workspace, hdr, dx, lddx, residual, ldr, nullptr, nullptr, B, H, W, Cout, Cin, k, 1, st, bf);
 }
 
-size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k) {
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0) return 0;
+size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || k <= 0 || (stride != 1 && stride != 2)) return 0;
+    if (stride == 2) { H = (H + 1) / 2; W = (W + 1) / 2; }  // the K dimension runs over the dy grid
     int ntn, ntj, splits, sps;
     // the larger of the two modes' split counts (the mode may be switched between the size query and the call)
     size_t most = 0;
@@ -1018,7 +1030,7 @@ size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, 
 }
 
 int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, float* dw,
-                               int B, int H, int W, int Cin, int Cout, int k,
+                               int B, int H, int W, int Cin, int Cout, int k, int stride,
                                void* workspace, size_t workspace_bytes, const unsigned* x_amax, const unsigned* dy_amax,
                                void* stream) {
     if (!x_planes || !dy_planes || !dw) return Y4_ERR_NULL;
@@ -1028,8 +1040,8 @@ int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, floa
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31) || (k != 1 && k != 3)) return Y4_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(dy_planes) & 15) ||
         (reinterpret_cast<uintptr_t>(dw) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return Y4_ERR_SHAPE;
-    if (workspace_bytes < y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k)) return Y4_ERR_WORKSPACE;
-    return y4::planes_wgrad(x_planes, x_amax, dy_planes, dy_amax, dw, workspace, workspace_bytes, B, H, W, Cin, Cout, k, y4_stream(stream), bf);
+    if (workspace_bytes < y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;
+    return y4::planes_wgrad(x_planes, x_amax, dy_planes, dy_amax, dw, workspace, workspace_bytes, B, H, W, Cin, Cout, k, y4_stream(stream), bf, stride);
 }
 
 }  // extern "C"

@@ -462,7 +462,8 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const double* __restrict__ acc, float* __restrict__ dy, long long lddy,
-    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds, int frozen, int bf) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds, int frozen, int bf,
+    float* __restrict__ twin) {
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     const double invM = frozen ? 0.0 : 1.0 / (double)M;    // frozen statistics: no batch-statistic terms in dy
@@ -518,7 +519,9 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
                 if (bf) {
                     store_bf16x4(reinterpret_cast<unsigned char*>(dy + m * lddy), c0, o);      // conv mode 2: plain bf16, no scale
                 } else if (bounds) {
-                    store_planes4(reinterpret_cast<unsigned char*>(dy + m * lddy), c0, o, ps, paired);
+                    // twin: dy stays fp32 for a register-staged dgrad, the pre-split copy (dense rows) goes to the plane wgrad
+                    store_planes4(reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : dy + m * lddy), c0, o, ps, paired);
+                    if (twin) st4(dy + m * lddy + c0, o);
                 } else {
                     st4(dy + m * lddy + c0, o);
                     amax_track(amax, o);
@@ -915,11 +918,12 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
                            const float* mean, const float* invstd, const float* gamma, const float* beta,
                            int act, float* dy, int lddy, float* dgamma, float* dbeta,
                            long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                           unsigned* f16_planes, int flags, void* stream) {
+                           unsigned* f16_planes, float* planes_twin, int flags, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
     const int frozen = flags & 1, bf = (flags >> 1) & 1;
     if (frozen && f16_planes) return Y4_ERR_SHAPE;         // (the plane bound is derived for batch statistics)
     if (bf && (f16_planes || lddy != C || (C & 31))) return Y4_ERR_SHAPE;
+    if (planes_twin && (!f16_planes || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);
@@ -937,7 +941,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
         const int rc = fold_partials(part, rblocks, C, bacc, &nb, st);
         if (rc != Y4_OK) return rc;
     }
-    if (f16_planes && (lddy != C || (C & 31))) return Y4_ERR_SHAPE;       // planes: dense rows, whole 32-channel K-tiles
+    if (f16_planes && ((!planes_twin && lddy != C) || (C & 31))) return Y4_ERR_SHAPE;       // planes: dense rows, whole 32-channel K-tiles
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta, gamma,
                        invstd, 1.0 / (double)M, f16_planes);
     Y4_CHECK_LAUNCH();
@@ -945,7 +949,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
                        (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,
-                       out_amax, f16_planes, frozen ? 1 : 0, bf);
+                       out_amax, f16_planes, frozen ? 1 : 0, bf, planes_twin);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -954,9 +958,9 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                       const float* mean, const float* invstd, const float* gamma, const float* beta,
                       int act, float* dy, int lddy, float* dgamma, float* dbeta,
                       long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
-                      unsigned* f16_planes, int frozen_stats, void* stream) {
+                      unsigned* f16_planes, float* planes_twin, int frozen_stats, void* stream) {
     return bn_act_bwd_impl(dz, lddz, y, ldy, mean, invstd, gamma, beta, act, dy, lddy, dgamma, dbeta, M, C, workspace,
-                           workspace_bytes, out_amax, f16_planes, frozen_stats, stream);
+                           workspace_bytes, out_amax, f16_planes, planes_twin, frozen_stats, stream);
 }
 
 static int colsum_rows(long long M) { return (int)(M < 1024 ? M : 1024); }

@@ -64,7 +64,7 @@ class ConvBNAct(nn.Module):
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
                'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes,
-               'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self) else None,
+               'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self, x.shape[2:]) else None,
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:
             use_batch_stats = self.training or n.running_mean is None
@@ -115,11 +115,14 @@ def soft(want, *mods):
     return 'both' if (want is True and observed(*mods)) else want
 
 
-def takes_planes(m):
-    """True if ConvBNAct `m` can consume a pre-split (planes) input right now: training-mode BatchNorm, conv mode 3,
-    stride 1, whole 32-channel K tiles on both sides and at least one full 128-column tile of output channels (all three
-    of its convs then run on the DMA kernels of csrc/conv_planes.hip)."""
-    if not isinstance(m, ConvBNAct) or not m.has_bn or not m.training or m.stride != 1:
+def takes_planes(m, hw=None):
+    """True if ConvBNAct `m` can consume a pre-split (planes) input right now: training-mode BatchNorm, conv mode 3 (or 2),
+    whole 32-channel K tiles on both sides and at least one full 128-column tile of output channels; stride 1 (all three
+    of its convs then run on the DMA kernels of csrc/conv_planes.hip), or a 3x3 stride-2 layer on an even map `hw` = (H, W)
+    of its input (forward and wgrad on the DMA kernels, dgrad on the register-staged parity-class kernel)."""
+    if not isinstance(m, ConvBNAct) or not m.has_bn or not m.training:
+        return False
+    if m.stride != 1 and not (hw is not None and ops.planes_stride2_ok(m.kernel_size, m.stride, int(hw[0]), int(hw[1]))):
         return False
     ci, co = m.conv.in_channels, m.conv.out_channels
     if ci % 32 or co % 32 or co < 128 or ci < 64 or m.kernel_size not in (1, 3):
@@ -128,6 +131,17 @@ def takes_planes(m):
         return False
     pm = ops.planes_mode()
     return pm == 'f16x2' or (pm == 'bf16' and ci % 64 == 0 and co % 64 == 0)     # bf16 rows hold 64 channels
+
+
+def plan_for(consumers, hw):
+    """out_planes request for a tensor of spatial size hw read by the ConvBNAct modules `consumers`: True if its single reader
+    takes planes, 'both' if one of several does (or somebody is looking), else False."""
+    takers = [m for m in consumers if takes_planes(m, hw)]
+    if not takers:
+        return False
+    if len(consumers) == 1:
+        return soft(True, consumers[0])
+    return 'both'
 
 
 def chain(seq, x, last=False):
@@ -200,13 +214,15 @@ class CSPDownSample0(nn.Module):
         self.part2_2 = ConvBNAct(out_ch, out_ch, 1, 1, act=act)
         self.transition = ConvBNAct(out_ch * 2, out_ch, 1, 1, act=act)
 
-    def forward(self, x):
+    def forward(self, x, readers=None):
+        """readers: the ConvBNAct modules that will read the result (the reference's forward has no such argument): where they
+        take pre-split inputs the transition conv writes its result that way."""
         xa, xb = ops.fork(self.base(x))
         cb = ops.cat_buffer(xa, [self.part2_2.conv.out_channels, self.part1.conv.out_channels])
         x1 = self.part1(xa, out=cb.slot(1))
         x2 = res_unit(self.part2_1_2, self.part2_1_1(xb))
         x2 = self.part2_2(x2, out=cb.slot(0))
-        return self.transition(ops.cat([x2, x1], into=cb))
+        return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)
 
 
 class CSPDownSample(nn.Module):
@@ -220,7 +236,8 @@ class CSPDownSample(nn.Module):
                                    ConvBNAct(out_ch // 2, out_ch // 2, 1, 1, act=act))
         self.transition = ConvBNAct(out_ch, out_ch, 1, 1, act=act)
 
-    def forward(self, x):
+    def forward(self, x, readers=None):
+        """readers: as CSPDownSample0.forward."""
         # both consumers of the stride-2 conv's result are 1x1 convs: where both take planes the result leaves pre-split only
         both = soft(bool(_TWIN_RES and takes_planes(self.part1) and takes_planes(self.part2[0])), self.part1, self.part2, self.part2[0])
         xa, xb = ops.fork(self.base(x, out_planes=both))
@@ -228,11 +245,11 @@ class CSPDownSample(nn.Module):
         x1 = self.part1(xa, out=cb.slot(1))
         if observed(self.part2):
             x2 = self.part2(xb)                      # hooks on the Sequential: the plain call; cat copies its result in
-            return self.transition(ops.cat([x2, x1], into=cb))
+            return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)
         blk = self.part2[1]
         # part2[0]'s result feeds the first unit's 1x1 conv and its skip; the block's result feeds part2[2] alone
         first = 'both' if (blk.shortcut and blk.first_takes_planes()) else False
         last = soft(bool(blk.shortcut and _TWIN_RES and takes_planes(self.part2[2])), blk, self.part2[2])
         x2 = blk(self.part2[0](xb, out_planes=first), out_planes=last)
         x2 = self.part2[2](x2, out=cb.slot(0))
-        return self.transition(ops.cat([x2, x1], into=cb))
+        return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)

@@ -229,6 +229,11 @@ def fast_conv_shape(Cin, k, s):
     return k in (1, 3) and s in (1, 2) and (Cin % 32 == 0 or (Cin == 3 and k == 3 and s == 1))
 
 
+def planes_stride2_ok(k, s, H, W):
+    """The 3x3 stride-2 layers run on the plane kernels (forward; wgrad with x read at 4 p - 2 w) on even maps, f16x2 only."""
+    return s == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and planes_mode() == 'f16x2'
+
+
 def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
                  out_amax=None, w_prepared=None):
     L = lib()
@@ -454,8 +459,8 @@ def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None, prepared=None):
     return dx
 
 
-def conv_wgrad_planes_raw(xp, dyp, w_shape, k, out=None):
-    """dW of a stride-1 conv from Planes x and dy; `out` as conv_wgrad_raw."""
+def conv_wgrad_planes_raw(xp, dyp, w_shape, k, out=None, s=1):
+    """dW of a conv from Planes x and dy (stride 1, or the 3x3 stride-2 layers on even maps); `out` as conv_wgrad_raw."""
     L = lib()
     B, Cin, H, W = xp.shape
     Cout = w_shape[0]
@@ -465,9 +470,9 @@ def conv_wgrad_planes_raw(xp, dyp, w_shape, k, out=None):
     else:
         WGRAD_STATS['temporary'] += 1
         dw = krsc(torch.empty(w_shape, device=xp.buf.device, dtype=torch.float32).contiguous(memory_format=CL))
-    nbytes = L.y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k)
+    nbytes = L.y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k, s)
     ws = _ws(nbytes, xp.buf.device)
-    check(L.y4_conv2d_wgrad_planes_f32(_ptr(xp.buf), _ptr(dyp.buf), _ptr(dw), B, H, W, Cin, Cout, k, _ptr(ws), nbytes,
+    check(L.y4_conv2d_wgrad_planes_f32(_ptr(xp.buf), _ptr(dyp.buf), _ptr(dw), B, H, W, Cin, Cout, k, s, _ptr(ws), nbytes,
                                        _ptr(xp.amax), _ptr(dyp.amax), _stream()), 'conv2d_wgrad_planes')
     return dw
 
@@ -636,8 +641,9 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
 
 
 def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None,
-                   frozen=False, bf16=False):
-    """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket)."""
+                   frozen=False, bf16=False, twin=False):
+    """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket).
+    twin (with planes): dy stays fp32 and the pre-split copy is returned beside it: (dy, dgamma, dbeta, dy_planes)."""
     L = lib()
     B, C, H, W = y.shape
     dz, lddz = as_nhwc(dz)
@@ -648,12 +654,16 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
         ok = t is not None and t.dtype == torch.float32 and tuple(t.shape) == (C,) and t.is_contiguous() and t.is_cuda
         return t if ok else torch.empty(C, device=y.device, dtype=torch.float32)
     dgamma, dbeta = slot(dgamma_out), slot(dbeta_out)
+    dyp = empty_nhwc(B, C, H, W, y.device) if twin else None
     nbytes = L.y4_bn_workspace(B * H * W, C)
     ws = _ws(nbytes, y.device)
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
-                              _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), (1 if frozen else 0) | (2 if bf16 else 0), _stream()),
+                              _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), _ptr(dyp) if twin else None,
+                              (1 if frozen else 0) | (2 if bf16 else 0), _stream()),
           'bn_act_bwd')
+    if twin:
+        return dy, dgamma, dbeta, dyp
     return dy, dgamma, dbeta
 
 
@@ -784,7 +794,8 @@ class ConvBNActFn(torch.autograd.Function):
         if xp is None and cfg.get('x_twin') is not None:
             xp = planes_of(cfg['x_twin'])            # x itself is fp32 (it has other consumers); its pre-split twin feeds this conv
         ctx.x_planes = xp is not None
-        if xp is not None and not ((f16 or bfm) and bn and training and s == 1 and weight.shape[0] % 32 == 0 and x.shape[1] % 32 == 0):
+        if xp is not None and not ((f16 or bfm) and bn and training and weight.shape[0] % 32 == 0 and x.shape[1] % 32 == 0
+                                   and (s == 1 or planes_stride2_ok(k, s, x.shape[2], x.shape[3]))):
             raise Y4Error('a pre-split (planes) tensor reached a conv that cannot consume it')
         x_amax = live(cfg.get('x_amax')) if f16 else None
         z_amax = None
@@ -877,7 +888,7 @@ class ConvBNActFn(torch.autograd.Function):
         cfg = ctx.cfg
         k, s, act = cfg['k'], cfg['s'], cfg['act']
         f16 = f16x2_mode() and ctx.x_shape[1] != 3
-        dy_amax = None
+        dy_amax = dy_pl = None
         x_amax = live(ctx.x_amax)                     # None if the ring recycled it since forward: wgrad takes its own pass
         x_planes = getattr(ctx, 'x_planes', False)
         if ctx.mode in ('bn_train', 'bn_eval_grad'):
@@ -891,10 +902,15 @@ class ConvBNActFn(torch.autograd.Function):
             bfp = x_planes and planes_mode() == 'bf16'       # conv mode 2: dy leaves as plain bf16, no scale word
             planes = planes_cell(dz.device, 8) if (x_planes and not bfp) else None
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
-            dy, dgamma, dbeta = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
-                                               gp.grad if sink else None, bp.grad if sink else None,
-                                               out_amax=None if planes is not None else dy_amax, planes=planes,
-                                               frozen=ctx.mode == 'bn_eval_grad', bf16=bfp)
+            # stride 2 over planes: wgrad runs on the plane kernel, dgrad on the register-staged parity-class kernel, which
+            # wants fp32 -- dy leaves the sweep both ways (the bound in word [5] dominates max|dy|: it serves both as scale)
+            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0]
+            res = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
+                                 gp.grad if sink else None, bp.grad if sink else None,
+                                 out_amax=None if planes is not None else dy_amax, planes=planes,
+                                 frozen=ctx.mode == 'bn_eval_grad', bf16=bfp, twin=twin_dy)
+            dy, dgamma, dbeta = res[:3]
+            dy_pl = res[3] if twin_dy else dy
             if sink and dgamma is gp.grad and dbeta is bp.grad:
                 # written straight into the (zeroed) DDP gradient slots: no temporaries, no accumulate kernels
                 gp._y4_grad_fresh = bp._y4_grad_fresh = False
@@ -919,7 +935,7 @@ class ConvBNActFn(torch.autograd.Function):
                 dx = conv_stem_dgrad_raw(dy, weight, x)       # gradient wrt the network input (never needed in training)
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
-            elif x_planes:
+            elif x_planes and s == 1:
                 dx = conv_dgrad_planes_raw(Planes(dy, dy.shape, dy_amax), weight, ctx.x_shape, k, residual=skip_grad,
                                            prepared=getattr(ctx, 'dgrad_filter', None))
             else:
@@ -934,8 +950,8 @@ class ConvBNActFn(torch.autograd.Function):
 
             def wgrad(out=None):
                 if x_planes:
-                    return conv_wgrad_planes_raw(Planes(x, x.shape, ctx.x_amax), Planes(dy, dy.shape, dy_amax),
-                                                 tuple(weight.shape), k, out=out)
+                    return conv_wgrad_planes_raw(Planes(x, ctx.x_shape, ctx.x_amax), Planes(dy_pl, dy.shape, dy_amax),
+                                                 tuple(weight.shape), k, out=out, s=s)
                 return conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=out, x_amax=x_amax, dy_amax=dy_amax)
             if _ASYNC['on'] and param is not None and param.requires_grad:
                 # lands in param.grad on the side stream

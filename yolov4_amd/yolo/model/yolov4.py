@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from ... import ops
-from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain, observed, soft, takes_planes
+from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain, observed, plan_for, soft, takes_planes
 from .yololayer import YOLOLayer
 
 L = 'leaky_relu'
@@ -33,13 +33,18 @@ class Backbone(nn.Module):
         self.stage4 = CSPDownSample(256, 512, 3, 2, num_blocks=8, act='mish')
         self.stage5 = CSPDownSample(512, 1024, 3, 2, num_blocks=4, act='mish')
 
-    def forward(self, x):
-        x = self.stage2(self.stage1(self.stem(x)))
-        x3 = self.stage3(x)
+    def forward(self, x, readers=((), (), ())):
+        """readers: the ConvBNAct modules outside the backbone that read x3 / x4 / x5 (YOLOv4.forward names the neck's), so
+        that a stage's transition conv can write its result pre-split where its readers take it so (the reference's
+        forward has no such argument; hooks on this module or on a stage keep everything fp32: darknet.observed)."""
+        quiet = not observed(self)
+        x = self.stage1(self.stem(x), readers=[self.stage2.base] if quiet and not observed(self.stage2) else None)
+        x = self.stage2(x, readers=[self.stage3.base] if quiet and not observed(self.stage3) else None)
+        x3 = self.stage3(x, readers=[self.stage4.base] + list(readers[0]))
         x3a, x3b = ops.fork(x3)
-        x4 = self.stage4(x3a)
+        x4 = self.stage4(x3a, readers=[self.stage5.base] + list(readers[1]))
         x4a, x4b = ops.fork(x4)
-        x5 = self.stage5(x4a)
+        x5 = self.stage5(x4a, readers=list(readers[2]) if quiet else None)
         return x3b, x4b, x5
 
 
@@ -136,7 +141,8 @@ class PANBlock(nn.Module):
         cb = ops.cat_buffer(f2, [256, f2.shape[1]])
         p2 = self.conv1(f1b, out=cb.slot(0))
         assert p2.shape[2:] == f2.shape[2:]
-        p2 = chain(self.module1, ops.cat([p2, f2], into=cb), last='both' if head_planes[0] else False)
+        p2 = chain(self.module1, ops.cat([p2, f2], into=cb),
+                   last='both' if (head_planes[0] or takes_planes(self.conv7, p2.shape[2:])) else False)
         p2a, p2b = ops.fork(p2)
         cb = ops.cat_buffer(f3, [512, f3.shape[1]])
         p3 = self.conv7(p2a, out=cb.slot(0))
@@ -156,7 +162,9 @@ class Neck(nn.Module):
     def forward(self, x3, x4, x5, head_planes=(False, False, False)):
         """head_planes: which of the three head 3x3 convs take pre-split inputs (YOLOv4.forward asks them)."""
         x5 = self.spp(x5, out_planes=soft(takes_planes(self.fpn.module1[0]), self.fpn, self.fpn.module1, self.fpn.module1[0]))
-        return self.pan(*self.fpn(x3, x4, x5, head_planes=head_planes[0]), head_planes=head_planes[1:])
+        # f1 is read by head.yolo1[0] and by the stride-2 conv pan.conv1: either taking planes asks for the pre-split twin
+        f1_twin = head_planes[0] or takes_planes(self.pan.conv1, x3.shape[2:])
+        return self.pan(*self.fpn(x3, x4, x5, head_planes=f1_twin), head_planes=head_planes[1:])
 
 
 class Head(nn.Module):
@@ -216,7 +224,10 @@ class YOLOv4(nn.Module):
         # (True: the head conv may be the SOLE reader of a pre-split tensor; 'both' where somebody may be looking on the way)
         hp = tuple(soft(takes_planes(h[0]), self.neck, self.neck.pan, self.head, h, h[0])
                    for h in (self.head.yolo1, self.head.yolo2, self.head.yolo3))
-        p1, p2, p3 = self.neck(*self.backbone(x), head_planes=hp)
+        # who reads the backbone's three results: fpn.conv11 (x3), fpn.conv4 (x4), the first conv of the SPP block (x5, alone)
+        seen = observed(self.backbone, self.neck, self.neck.spp, self.neck.spp.conv1, self.neck.fpn)
+        readers = ((self.neck.fpn.conv11,), (self.neck.fpn.conv4,), () if seen else (self.neck.spp.conv1[0],))
+        p1, p2, p3 = self.neck(*self.backbone(x, readers=readers), head_planes=hp)
         if self.training:
             return list(self.head(p1, p2, p3))
         if observed(self.head, self.head.yolo1, self.head.yolo2, self.head.yolo3):
