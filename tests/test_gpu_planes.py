@@ -57,7 +57,8 @@ def test_planes_forward_matches_torch_and_the_register_staged_kernel(dev, case):
     assert float((y - y0).abs().max()) <= 2e-6 * float(ref.abs().max())
     # column sums of the epilogue = sums of the stored result
     M = y.shape[0] * y.shape[2] * y.shape[3]
-    assert n == ((M + 127) // 128 if k * k * ci <= 256 else (M + 255) // 256)      # 128-row tiles for short K (conv_planes.hip)
+    # 128-row tiles for short K, and where 256-row tiles would fill the last round of CUs badly (conv_planes.hip: planes_conv)
+    assert n == (M + 127) // 128 if k * k * ci <= 256 else n in ((M + 127) // 128, (M + 255) // 256)
     ps = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()), dtype=torch.float32)[:n * 2 * co].view(n, 2, co).double().sum(0)
     yy = y.double().cpu().permute(0, 2, 3, 1).reshape(-1, co)
     assert torch.allclose(ps[0], yy.sum(0), rtol=1e-5, atol=1e-4 * float(yy.abs().max()))

@@ -811,7 +811,19 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
     // short K (1x1 layers up to 256 input channels): the two-blocks-per-CU shape (3-8 % faster there, measured; from K = 512
     // on the 256-row shape wins again).  Y4_PLANES_SMALL = 0 never, 2 always (experiments)
     static const int small_mode = getenv("Y4_PLANES_SMALL") ? atoi(getenv("Y4_PLANES_SMALL")) : 1;
-    const bool small = small_mode == 2 || (small_mode == 1 && g.K <= 256);
+    // ... and grids that quantise badly on 256 CUs with 256-row tiles (e.g. 364 blocks = 1.42 rounds at 19 x 19): in units of
+    // the time of ONE 128-row block alone on a CU, a round of 256-row blocks costs 2; 128-row blocks sit two per CU, a full
+    // round of 512 costs 2, a last round of <= 256 blocks (one per CU) costs 1 (the two shapes run long K at the same rate)
+    bool quant = false;
+    {
+        const long long nt = (N + 127) / 128;
+        const long long b256 = (long long)((g.M + 255) / 256) * nt, b128 = (long long)((g.M + 127) / 128) * nt;
+        const long long c256 = ((b256 + 255) / 256) * 2;
+        const long long tail = b128 % 512;
+        const long long c128 = (b128 / 512) * 2 + (tail == 0 ? 0 : (tail <= 256 ? 1 : 2));
+        quant = (double)c128 * 1.08 < (double)c256;
+    }
+    const bool small = small_mode == 2 || (small_mode == 1 && (g.K <= 256 || quant)) || (small_mode == 4 && g.K <= 256);   // 4: short K only
     if (bf) {
         // 256 x 256 (wave tile 128 x 64) unless its grid quantises badly on 256 CUs or N fits one 128-column tile
         const char* bt = getenv("Y4_BF_TILE");             // experiments / tests: 1: 256x128 always, 2: 256x256 always

@@ -231,7 +231,10 @@ def fast_conv_shape(Cin, k, s):
 
 def planes_stride2_ok(k, s, H, W):
     """The 3x3 stride-2 layers run on the plane kernels (forward; wgrad with x read at 4 p - 2 w) on even maps, f16x2 only."""
-    return s == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and planes_mode() == 'f16x2'
+    return s == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and planes_mode() == 'f16x2' and _S2_PLANES
+
+
+_S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
 
 
 def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
@@ -955,7 +958,9 @@ class ConvBNActFn(torch.autograd.Function):
                 return conv_wgrad_raw(x, dy, tuple(weight.shape), k, s, out=out, x_amax=x_amax, dy_amax=dy_amax)
             if _ASYNC['on'] and param is not None and param.requires_grad:
                 # lands in param.grad on the side stream
-                _wgrad_to_param(x, dy, param, k, s, ctx.x_amax if x_planes else x_amax, dy_amax, fn=wgrad if x_planes else None)
+                # (the operand the side stream reads: for a stride-2 plane layer that is the pre-split twin of dy)
+                _wgrad_to_param(x, dy_pl if x_planes else dy, param, k, s, ctx.x_amax if x_planes else x_amax, dy_amax,
+                                fn=wgrad if x_planes else None)
             elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
                 # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place
                 # (no temporary, no accumulate pass); the bucket is told directly, autograd gets None
