@@ -132,3 +132,59 @@ def test_tile_kernel_on_channel_slices(dev):
     assert ops.last_conv_kernel().startswith('conv3x3_tile_f16x2')
     dref = torch.nn.grad.conv2d_input((B, 32, H, W), w.double(), dyw[:, 64:128].double().cpu(), 1, 1) + resw[:, 32:64].double().cpu()
     assert float((dx.double().cpu() - dref).abs().max()) <= 1e-5 * float(dref.abs().max())
+
+
+# ---------------------------------------------------------------- csrc/wgrad_tile.hip: filter gradient of the same family of layers
+WGRAD_CASES = [
+    # B, Cin, Cout, stride, H, W   (input map)
+    (2, 32, 64, 1, 112, 112),
+    (1, 64, 64, 1, 104, 120),      # two 32-channel input groups
+    (3, 32, 64, 1, 101, 107),      # odd sides: partial tiles right and below
+    (2, 32, 64, 2, 208, 208),      # stride 2: patch de-interleaved by column parity
+    (1, 32, 64, 2, 202, 230),      # stride 2, output 101 x 115: partial tiles
+    (70, 64, 64, 1, 100, 104),     # more tiles than one block's share many times over, many images
+]
+
+
+@pytest.mark.parametrize('case', WGRAD_CASES)
+def test_tile_wgrad_matches_torch_and_the_split_k_kernel(dev, case, monkeypatch):
+    from yolov4_amd import ops
+    B, ci, co, s, H, W = case
+    x = recipe.randn((B, ci, H, W), 41)
+    Ho, Wo = (H + 2 - 3) // s + 1, (W + 2 - 3) // s + 1
+    dy = recipe.randn((B, co, Ho, Wo), 42)
+    xd, dyd = cl(x, dev), cl(dy, dev)
+    dw = ops.conv_wgrad_raw(xd, dyd, (co, ci, 3, 3), 3, s)
+    torch.cuda.synchronize()
+    assert ops.last_conv_kernel().startswith('wgrad_tile_f16x2'), ops.last_conv_kernel()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (co, ci, 3, 3), dy.double(), s, 1)
+    err = float((dw.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 3e-6, err
+    # same arithmetic as the split-K kernel it replaces (same scales, same pieces): equal to accumulation order
+    monkeypatch.setenv('Y4_NO_TILE_WGRAD', '1')
+    dw2 = ops.conv_wgrad_raw(xd, dyd, (co, ci, 3, 3), 3, s)
+    # (the switch is read once per process: if this process already used the tile kernel, the second call is the same kernel)
+    assert float((dw - dw2).abs().max()) <= 3e-6 * float(ref.abs().max())
+    # deterministic: fixed tile order per block, fixed-order slab reduce
+    dw3 = ops.conv_wgrad_raw(xd, dyd, (co, ci, 3, 3), 3, s)
+    if ops.last_conv_kernel().startswith('wgrad_tile_f16x2'):
+        assert torch.equal(dw3, ops.conv_wgrad_raw(xd, dyd, (co, ci, 3, 3), 3, s))
+
+
+def test_tile_wgrad_on_channel_slices_and_wide_dynamic_range(dev):
+    """x a channel slice of a wider NHWC buffer (pitch 96), dy with pitch 128; x of order 1e4 with a 1e8 outlier, dy of order
+    1e-6: the per-tensor power-of-two scales keep 22 significant bits (as the other f16x2 kernels)."""
+    from yolov4_amd import ops
+    B, ci, co, H, W = 2, 32, 64, 112, 104
+    xw = torch.randn(B, 96, H, W, device=dev).contiguous(memory_format=torch.channels_last) * 1e4
+    xw[0, 40, 5, 7] = 1e8
+    x = xw[:, 32:64]
+    dyw = torch.randn(B, 128, H, W, device=dev).contiguous(memory_format=torch.channels_last) * 1e-6
+    dy = dyw[:, 64:128]
+    dw = ops.conv_wgrad_raw(x, dy, (co, ci, 3, 3), 3, 1)
+    torch.cuda.synchronize()
+    assert ops.last_conv_kernel().startswith('wgrad_tile_f16x2'), ops.last_conv_kernel()
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (co, ci, 3, 3), dy.double().cpu(), 1, 1)
+    # the outlier costs the other elements of x their low bits (scale follows the maximum): bound relative to |x|max |dy| sums
+    bound = 1e8 * 2.0 ** -22 * float(dy.abs().sum(dim=(0, 2, 3)).max())
+    assert float((dw.double().cpu() - ref).abs().max()) <= max(3e-6 * float(ref.abs().max()), bound)

@@ -74,6 +74,12 @@ int f16x2_tile(const ConvGeom& g, hipStream_t st, int* nparts);
 bool tile_dgrad_s2_ok(int Cs, int Cs_valid, int N, int k, int stride, int Hs, int Ws);
 int f16x2_tile_dgrad_s2(const ConvGeom& g, hipStream_t st);      // dgrad of a stride-2 3x3 conv, all four parity classes per tile
 
+// wgrad_tile.hip: filter gradient of the 3x3 layers with 32 / 64 input channels and 64 output channels on large maps
+// (x patch and dy tile staged once per tile of outputs, all nine taps out of LDS, the whole dW slice in one block's accumulators)
+bool tile_wgrad_ok(int Cin, int Cout, int k, int stride, int H, int W, long long ldx, long long lddy);
+int tile_wgrad_slabs(int Cin, int Cout);
+int f16x2_wgrad_tile(const WgradGeom& g, hipStream_t st);     // g.out: g.splits (= tile_wgrad_slabs) slabs of [Cout][9 Cin]
+
 // conv_planes.hip: DMA-fed kernels over pre-split operands
 bool planes_conv_ok(int Cin, int Cout, int k, int stride);
 int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,

@@ -1985,8 +1985,10 @@ int y4_conv2d_fwd_prepared_f32(const float* x, int ldx, void* w_prepared, float*
 size_t y4_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride) {
     WgradGeom g{};
     wgrad_plan(B, H, W, Cin, Cout, k, stride, g);
-    // slabs of the split-K partial sums + 64 B of amax words (f16x2 mode)
-    return (g.splits > 1 ? (size_t)g.splits * Cout * g.J * sizeof(float) : 0) + 64;
+    // slabs of the split-K partial sums + 64 B of amax words (f16x2 mode); the tile kernel (wgrad_tile.hip) writes one slab per block
+    int splits = g.splits;
+    if (y4::tile_wgrad_ok(Cin, Cout, k, stride, H, W, 0, 0) && y4::tile_wgrad_slabs(Cin, Cout) > splits) splits = y4::tile_wgrad_slabs(Cin, Cout);
+    return (splits > 1 ? (size_t)splits * Cout * g.J * sizeof(float) : 0) + 64;
 }
 
 int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, float* dw,
@@ -2010,6 +2012,9 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
         if (range_px * per_px >= 0xfffffff0ull) return Y4_ERR_SHAPE;      // pitch more than 2x the channel count at > 4 GiB
     }
     hipStream_t st = y4_stream(stream);
+    // few channels on a large map (3x3): the tile kernel -- every x pixel staged once for nine taps, one slab per block
+    const bool tile = g_conv_mode == 3 && y4::tile_wgrad_ok(Cin, Cout, k, stride, H, W, ldx, lddy);
+    if (tile) g.splits = y4::tile_wgrad_slabs(Cin, Cout);
     const size_t slab_bytes = g.splits > 1 ? (size_t)g.splits * Cout * g.J * sizeof(float) : 0;
     if (g.splits > 1) {
         if (!workspace) return Y4_ERR_NULL;
@@ -2035,7 +2040,7 @@ int y4_conv2d_wgrad_f32(const float* x, int ldx, const float* dy, int lddy, floa
             }
         }
         g.x_amax = x_amax; g.dy_amax = dy_amax;
-        rc = y4::f16x2_wgrad(g, st);
+        rc = tile ? y4::f16x2_wgrad_tile(g, st) : y4::f16x2_wgrad(g, st);
     } else if (g_conv_mode == 1) {
         if (g.tn == 128 && g.tj == 128) rc = launch_wgrad<128, 128, 3>(g, st);
         else if (g.tn == 128) rc = launch_wgrad<128, 64, 3>(g, st);
