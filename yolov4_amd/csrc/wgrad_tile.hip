@@ -14,8 +14,8 @@
 //     hardware transpose read; a filter tap is a constant row offset into the patch (stride 2: the patch is stored
 //     de-interleaved by column parity, so that the pixels a tap reads for 8 consecutive outputs are 8 consecutive rows);
 //   * two LDS images: the next tile's loads are in flight in registers under the MFMAs of the current one, one barrier per tile.
-// Wave w: output-channel tile w & 3 (16 of the 64), input-channel half w >> 2 (16 of the 32), nine taps: 27 MFMAs, 4 + 36
-// transposed reads per 32 pixels.
+// Wave w: output-channel tiles 2 (w & 1), + 1 (32 of the 64), input-channel half (w >> 1) & 1 (16 of the 32), taps 0-4 or 5-8
+// (w >> 2): 30 / 24 MFMAs, 8 + 20 / 16 transposed reads per 32 pixels.
 #include <stdlib.h>
 #include <type_traits>
 #include "common.h"
@@ -164,19 +164,26 @@ __global__ __launch_bounds__(512, 1) void wgrad_tile_f16x2(const TileWgradGeom g
     typedef __attribute__((address_space(3))) trh4* trp;
     static_assert((S == 1 ? 2 * PWS : 4 * PWS) % 16 == 0, "K-step stride must keep the swizzle");
     constexpr int KDELTA_B = (S == 1 ? 2 * PWS : 4 * PWS) * WROW, KDELTA_A = 32 * WROW;
-    const int nt = wave & 3, ch = wave >> 2;               // 16 output channels nt, input-channel half ch of the chunk
-    // dy rows of this lane in K-step 0: chunk nt >> 1, pixel 8 grp + qrow; segment (nt & 1) (hi), 2 + (nt & 1) (lo)
-    const int a_row0 = XROWS + (nt >> 1) * (TH * 16) + 8 * grp + qrow;
+    // wave -> (pair of output-channel tiles np: 32 of the 64, input-channel half ch: 16 of the 32, tap group tg: taps 0-4 / 5-8).
+    // Two row tiles share every x fragment: 8 + 20 transposed reads per 30 MFMAs and K-step (one row tile x nine taps per wave
+    // was 4 + 36 per 27, and the kernel is bound by its LDS reads)
+    const int np = wave & 1, ch = (wave >> 1) & 1, tg = wave >> 2;
+    const int ntap = tg ? 4 : 5;
+    // dy rows of this lane in K-step 0: chunk np, pixel 8 grp + qrow; row tile i: segment i (hi), 2 + i (lo)
+    const int a_row0 = XROWS + np * (TH * 16) + 8 * grp + qrow;
     // x rows of tap (0, 0) in K-step 0: output row grp >> 1, columns 8 (grp & 1) .. + 7
     const int b_row0 = (S == 1 ? (grp >> 1) * PWS : (grp >> 1) * 2 * PWS) + (grp & 1) * 8 + qrow;
-    int aoff[2][2], boff[9][2][2];                         // [plane][row / row + 4], [tap][plane][row / row + 4]
+    int aoff[2][2][2], boff[5][2][2];                      // [row tile][plane][row / row + 4], [tap of the group][plane][row / row + 4]
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) aoff[pl][h] = seg_addr(a_row0 + 4 * h, 2 * pl + (nt & 1)) + pp * 8;
+        for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int r = t / 3, q = t - 3 * r;
+            for (int h = 0; h < 2; ++h) aoff[i][pl][h] = seg_addr(a_row0 + 4 * h, 2 * pl + i) + pp * 8;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int tap = tg * 5 + t < 9 ? tg * 5 + t : 8;
+        const int r = tap / 3, q = tap - 3 * r;
         const int row = b_row0 + r * PWS + (S == 1 ? q : (q & 1) * T::ODD0 + (q >> 1));
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
@@ -192,29 +199,40 @@ __global__ __launch_bounds__(512, 1) void wgrad_tile_f16x2(const TileWgradGeom g
         return r;
     };
 
-    accv acc0[9], acc1[9];
+    accv acc0[2][5], acc1[2][5];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { acc0[t][e] = 0.f; acc1[t][e] = 0.f; }
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc0[i][t][e] = 0.f; acc1[i][t][e] = 0.f; }
 
     auto compute = [&](const unsigned char* img) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const unsigned char* ab = img + ks * KDELTA_A;     // (wave-uniform bases: one add per read, nothing to hoist)
             const unsigned char* bb = img + ks * KDELTA_B;
-            const f16x8 fa0 = frag(ab, aoff[0][0], aoff[0][1]), fa1 = frag(ab, aoff[1][0], aoff[1][1]);
+            f16x8 fa[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) fa[i][pl] = frag(ab, aoff[i][pl][0], aoff[i][pl][1]);
             f16x8 fb0, fb1, nb0, nb1;
             fb0 = frag(bb, boff[0][0][0], boff[0][0][1]); fb1 = frag(bb, boff[0][1][0], boff[0][1][1]);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                if (t < 8) {
-                    nb0 = frag(bb, boff[t + 1][0][0], boff[t + 1][0][1]);
-                    nb1 = frag(bb, boff[t + 1][1][0], boff[t + 1][1][1]);
+            for (int t = 0; t < 5; ++t) {
+                if (t + 1 < ntap) {                             // (wave-uniform)
+                    nb0 = frag(bb, boff[(t + 1) % 5][0][0], boff[(t + 1) % 5][0][1]);
+                    nb1 = frag(bb, boff[(t + 1) % 5][1][0], boff[(t + 1) % 5][1][1]);
                 }
-                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, fb0, acc1[t], 0, 0, 0);
-                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb0, acc0[t], 0, 0, 0);
-                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, fb1, acc1[t], 0, 0, 0);
+                if (t < ntap) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][1], fb0, acc1[i][t], 0, 0, 0);
+                        acc0[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb0, acc0[i][t], 0, 0, 0);
+                        acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][0], fb1, acc1[i][t], 0, 0, 0);
+                    }
+                }
                 fb0 = nb0; fb1 = nb1;
             }
         }
@@ -232,6 +250,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_tile_f16x2(const TileWgradGeom g
         const int nxt = tile + g.bpg;
         if (nxt < g.tiles) load_tile(nxt);                 // in flight under the MFMAs below
         compute(smem + cur * IMG);
+        // (dealing this split + store work out between the K-steps of the tile being computed measured +-0: 0.84 vs 0.83 ms)
         if (nxt < g.tiles) store_tile(smem + (cur ^ 1) * IMG);
         __syncthreads();                                   // image cur ^ 1 complete, image cur free for the tile after next
         cur ^= 1;
@@ -245,12 +264,17 @@ __global__ __launch_bounds__(512, 1) void wgrad_tile_f16x2(const TileWgradGeom g
     float* out = g.out + (long long)bi * g.Cout * J;
     const int fr = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 5; ++t) {
+        if (t >= ntap) continue;
+        const int tap = tg * 5 + t;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = n0 + nt * 16 + 4 * kq + e;
-            out[(long long)n * J + t * g.Cin + c0 + ch * 16 + fr] = acc0[t][e] * un + acc1[t][e] * un1;
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + (2 * np + i) * 16 + 4 * kq + e;
+                out[(long long)n * J + tap * g.Cin + c0 + ch * 16 + fr] = acc0[i][t][e] * un + acc1[i][t][e] * un1;
+            }
+    }
 }
 
 template <int S>
