@@ -72,7 +72,7 @@ def parse():
                          'stream time, 3 ms per step over all ~330 conv launches (implied by --conv-table)')
     ap.add_argument('--ddp-timeline', action='store_true',
                     help='record when each gradient bucket becomes ready inside the backward pass (adds ddp_timeline to the line)')
-    ap.add_argument('--conv-mode', default='f16x2', choices=['f16x2', 'bf16x3', 'f32', 'bf16'],
+    ap.add_argument('--conv-mode', default='f16x2', choices=['f16x2', 'bf16x3', 'f32', 'bf16', 'bf16_all'],
                     help='conv arithmetic: 2-piece fp16 split (fp32-grade, 3 MFMAs per product, default), exact 3-way bf16 '
                          'split (6 MFMAs), the fp32 MFMA fma chain, or plain bf16 operands (mixed precision)')
     ap.add_argument('--conv-table', default=None, help='write a per-shape conv timing table to this file')
@@ -306,9 +306,16 @@ MODES = {
                'peak_note': 'dense bf16 MFMA peak 2500 / 6 MFMAs per fp32-exact product',
                'text': 'bf16x3: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulate '
                        '(error <= the fp32-MFMA fma chain, see DESIGN.md)'},
-    'bf16': {'kk': 'bf16x3', 'mfmas': 1, 'peak': PEAK_BF16_MFMA_TFLOPS, 'instr': 'v_mfma_f32_32x32x16_bf16',
-             'peak_note': 'dense bf16 MFMA peak',
-             'text': 'plain bf16 MFMA operands (RN), fp32 accumulate; fp32 BN/loss/NMS (config 5, mixed precision)'},
+    'bf16': {'kk': 'f16x2', 'mfmas': 1, 'peak': PEAK_BF16_MFMA_TFLOPS, 'instr': 'v_mfma_f32_16x16x32_bf16',
+             'peak_note': 'dense bf16 MFMA peak (the dominant kernel runs ONE bf16 MFMA per product)',
+             'text': 'BASELINE configs[4], mixed precision: the layers on the DMA-fed plane kernels (72 of the 107 BatchNorm layers, '
+                     '9/10 of the conv flops) take plain bf16 operands (RN, written by the BatchNorm sweeps) and run one bf16 MFMA per '
+                     'product with fp32 accumulation; the remaining, HBM-bound layers keep the fp32-grade f16x2 kernels; BatchNorm '
+                     'statistics, loss and NMS in fp32 (yolov4_amd.set_conv_mode("bf16") = conv mode 3 + y4_set_planes_bf16)'},
+    'bf16_all': {'kk': 'bf16x3', 'mfmas': 1, 'peak': PEAK_BF16_MFMA_TFLOPS, 'instr': 'v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16',
+                 'peak_note': 'dense bf16 MFMA peak',
+                 'text': 'every conv operand rounded to bf16 (RN), one bf16 MFMA per product, fp32 accumulate; fp32 BN/loss/NMS '
+                         '(conv mode 2: plane layers on the bf16 DMA kernels, the others on the register-staged bf16 kernels)'},
     'f32': {'kk': 'mfma_f32', 'mfmas': 1, 'peak': PEAK_F32_MFMA_TFLOPS, 'instr': 'v_mfma_f32_32x32x2_f32',
             'peak_note': 'dense fp32 MFMA peak', 'text': 'fp32 MFMA fma chain (v_mfma_f32_32x32x2_f32)'},
 }
@@ -517,9 +524,10 @@ def main():
 
     import yolov4_amd
     yolov4_amd.set_conv_mode(args.conv_mode)
-    _ARGS['conv_mode'] = args.conv_mode
+    # (kernel names the library does not report itself are restated from the dispatch rules of the mode the non-plane layers run in)
+    _ARGS['conv_mode'] = {'bf16': 'f16x2', 'bf16_all': 'bf16'}.get(args.conv_mode, args.conv_mode)
     timer = ConvTimer()
-    all_events = args.all_kernel_events or bool(args.conv_table) or args.conv_mode != 'f16x2' or not ops.PLANES['on']
+    all_events = args.all_kernel_events or bool(args.conv_table) or args.conv_mode not in ('f16x2', 'bf16') or not ops.PLANES['on']
     if not args.no_kernel_events:
         timer.wrap(ops, only_dominant=not all_events)
 
@@ -584,7 +592,7 @@ def main():
             'metric': f'images/sec fwd+bwd @{S}x{S} bs={B} per GPU (YOLOv4 training step: forward + YOLOLoss + backward)',
             'value': value, 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16' if args.conv_mode == 'bf16' else 'f32', 'data': 'synthetic',
+            'dtype': 'bf16' if args.conv_mode in ('bf16', 'bf16_all') else 'f32', 'data': 'synthetic',
             'config': {'workload': f'configs[2]: 1xMI355X training step, {S}x{S} bs={B}/GPU, fwd+bwd+YOLOLoss HIP kernels, '
                                    f'synthetic targets (SURVEY 8d config 3); random-init weights',
                        'global_batch': world * B, 'img_size': S, 'parallelism': f'dp{world}',

@@ -68,6 +68,12 @@ int y4_device_count(void);
  *      out_amax) or, when NULL, from one extra pass over the operand inside the call. */
 int y4_set_conv_mode(int mode);
 int y4_get_conv_mode(void);
+/* BASELINE configs[4] ("bf16 MFMA conv, fp32 loss / NMS") as shipped: conv mode 3 with this switch on -- the layers that run on
+ * the DMA-fed plane kernels (72 of the 107 BatchNorm layers, 9/10 of the conv flops) take plain bf16 operands written by the
+ * BatchNorm sweeps and run one bf16 MFMA per product (y4_conv2d_*_planes_f32, y4_bn_act_fwd_f32 z_planes == 3); every other
+ * layer keeps the fp32-grade f16x2 kernels of mode 3, which are HBM-bound anyway.  (Mode 2 rounds EVERY conv operand to bf16.) */
+int y4_set_planes_bf16(int on);
+int y4_get_planes_bf16(void);
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d inside ConvBNAct.forward, darknet/darknet.py:31-36,53-54
  * (k in {1,3}, stride in {1,2}, pad=(k-1)//2, dilation 1, groups 1).

@@ -220,6 +220,7 @@ BF16_CASES = [
     # B, Cin, Cout, k, s, H, W
     (2, 64, 128, 3, 1, 9, 9),          # M = 162 < one tile
     (3, 64, 128, 3, 2, 13, 13),        # odd size, stride 2 (forward only)
+    (2, 128, 256, 3, 2, 20, 12),       # stride 2, even map: forward + wgrad
     (2, 128, 128, 1, 1, 12, 12),       # K = 128: the 128-row shape
     (5, 512, 256, 1, 1, 7, 7),         # tiles span several images; N = 256
     (2, 128, 256, 3, 1, 19, 19),       # M = 722 (ragged)
@@ -270,6 +271,11 @@ def test_bf16_planes_forward_dgrad_wgrad_are_exact_bf16_products(dev, bf16_mode,
     assert float((st[0] - yf.sum(0)).abs().max()) <= 1e-4 * max(float(yf.abs().sum(0).max()), 1e-6)
     assert float((st[1] - (yf * yf).sum(0)).abs().max()) <= 1e-4 * float((yf * yf).sum(0).max())
     if s != 1:
+        if H % 2 == 0 and W % 2 == 0:                # stride 2 on an even map: wgrad over planes, x read at 4 p - 2 w
+            dy2 = recipe.randn((B, co, H // 2, W // 2), 9)
+            dw2 = ops.conv_wgrad_planes_raw(xp, ops.planes_split_raw(cl(dy2, dev)), (co, ci, k, k), k, s=2)
+            ref2 = torch.nn.grad.conv2d_weight(_bf(x), (co, ci, k, k), _bf(dy2), 2, 1)
+            assert float((dw2.double().cpu() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
         return
     dy = recipe.randn((B, co, H, W), 9)
     dyd = cl(dy, dev)
@@ -284,7 +290,7 @@ def test_bf16_planes_forward_dgrad_wgrad_are_exact_bf16_products(dev, bf16_mode,
     assert float((dw.double().cpu() - dw_ref).abs().max()) <= 2e-6 * float(dw_ref.abs().max())
 
 
-def test_bf16_chain_and_resblock_through_planes_match_the_register_staged_bf16_path(dev, bf16_mode):
+def test_bf16_chain_and_resblock_through_planes_match_the_register_staged_bf16_path(dev):
     """Training-mode chains in conv mode 2 with pre-split (bf16) intermediates against the same modules with PLANES off (fp32
     tensors in HBM, rounded to bf16 while staged by the mode-2 register-staged kernels): the SAME bf16 operands reach the
     MFMAs either way, so results agree to accumulation order -- except that a dy rounded to bf16 by the BatchNorm backward
@@ -303,7 +309,6 @@ def test_bf16_chain_and_resblock_through_planes_match_the_register_staged_bf16_p
             nn.init.normal_(m.bias, 0, 0.1)
     x = torch.randn(3, 256, 19, 19, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = torch.randn(3, 128, 19, 19, device=dev).contiguous(memory_format=torch.channels_last)
-    assert takes_planes(seq[1]) and takes_planes(seq[2])
 
     def run(on):
         ops.PLANES['on'] = on
@@ -315,15 +320,17 @@ def test_bf16_chain_and_resblock_through_planes_match_the_register_staged_bf16_p
         torch.cuda.synchronize()
         return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(seq.parameters()) + list(rb.parameters())]
     import yolov4_amd
-    was = ops.PLANES['on']
+    was, old_mode = ops.PLANES['on'], yolov4_amd.get_conv_mode()
     try:
+        yolov4_amd.set_conv_mode('bf16_all')         # mode 2: EVERY conv in bf16, so that the two arms round the same operands
+        assert takes_planes(seq[1]) and takes_planes(seq[2])
         o1, gx1, gp1 = run(True)
         o0, gx0, gp0 = run(False)
         yolov4_amd.set_conv_mode('f16x2')            # the fp32-grade evaluation of the same graph: the yardstick
         ot, gxt, gpt = run(False)
     finally:
         ops.PLANES['on'] = was
-        yolov4_amd.set_conv_mode('bf16')
+        yolov4_amd.set_conv_mode(old_mode)
     # The two bf16 arms are not bit-equal: their fp32 pre-rounding values differ in the last bits (accumulation order), which
     # now and then flips a bf16 rounding (one bf16 ulp = 4e-3 of the element), and BatchNorm backward amplifies that.  What
     # must hold: each arm is an equally good bf16 evaluation of the graph -- the distance of the plane arm from the fp32-grade
@@ -412,3 +419,52 @@ def test_stride2_module_through_planes_matches_the_fp32_tensor_path(dev):
     assert float((gx1 - gx0).abs().max()) <= 2e-4 * float(gx0.abs().max())
     for p1, p0 in zip(gp1, gp0):
         assert float((p1 - p0).abs().max()) <= 2e-4 * max(float(p0.abs().max()), 1e-6)
+
+
+def test_hybrid_bf16_mode_runs_plane_layers_in_bf16_and_the_others_fp32_grade(dev):
+    """set_conv_mode('bf16') (BASELINE configs[4] as shipped): conv mode 3 + y4_set_planes_bf16 -- a 1x1 -> 3x3 stride-2 -> 1x1
+    chain in which the plane layers take bf16 operands (kernel names end in `true...>`) while a small-channel layer beside
+    them keeps the fp32-grade kernels; results within bf16 distance of the fp32-grade evaluation, gradients finite."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd.darknet.darknet import ConvBNAct, plan_for, takes_planes
+    from torch import nn
+    torch.manual_seed(29)
+    a = ConvBNAct(32, 128, 1, 1, act='mish').to(dev).train()        # Cin = 32: never a plane layer
+    b = ConvBNAct(128, 256, 3, 2, act='mish').to(dev).train()
+    c = ConvBNAct(256, 128, 1, 1, act='mish').to(dev).train()
+    for m in (a, b, c):
+        nn.init.uniform_(m.norm.weight, 0.8, 1.2)
+        nn.init.normal_(m.norm.bias, 0, 0.1)
+    x = torch.randn(3, 32, 20, 20, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wgt = torch.randn(3, 128, 10, 10, device=dev).contiguous(memory_format=torch.channels_last)
+    names = []
+
+    def run():
+        for p in list(a.parameters()) + list(b.parameters()) + list(c.parameters()):
+            p.grad = None
+        x.grad = None
+        z = a(x, out_planes=plan_for([b], x.shape[2:]))
+        names.append(ops.last_conv_kernel())
+        z = b(z, out_planes=plan_for([c], (10, 10)))
+        names.append(ops.last_conv_kernel())
+        out = c(z)
+        (out * wgt).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(a.parameters()) + list(b.parameters()) + list(c.parameters())]
+    old = yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode('bf16')
+        assert yolov4_amd.get_conv_mode() == 3 and ops.planes_mode() == 'bf16' and takes_planes(b, (20, 20))
+        o1, gx1, gp1 = run()
+        yolov4_amd.set_conv_mode('f16x2')
+        assert ops.planes_mode() == 'f16x2'
+        o0, gx0, gp0 = run()
+    finally:
+        yolov4_amd.set_conv_mode(old)
+    assert 'f16x2' in names[0] and 'true>' in names[1], names        # fp32-grade kernel for the 32-channel layer, bf16 planes for the 3x3
+    assert 'false' in names[3], names
+    for v1, v0 in [(o1, o0), (gx1, gx0)] + list(zip(gp1, gp0)):
+        assert bool(torch.isfinite(v1).all())
+        top = max(float(v0.abs().max()), 1e-6)
+        assert float((v1 - v0).abs().mean()) <= 2e-2 * top and float((v1 - v0).abs().max()) <= 0.15 * top

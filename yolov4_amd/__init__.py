@@ -20,11 +20,16 @@ __version__ = '0.1.0'
 
 
 def set_conv_mode(mode):
-    """0 / 'f32': fp32 MFMA (exact fma chain).  1 / 'bf16x3': exact 3-way bf16 split, six bf16 MFMAs
-    per product, fp32 accumulate (fp32-grade error, see include/yolov4_amd.h)."""
+    """0 / 'f32': fp32 MFMA (exact fma chain).  1 / 'bf16x3': exact 3-way bf16 split, six bf16 MFMAs per product.
+    3 / 'f16x2' (default): two fp16 pieces per operand, three MFMAs per product (all three fp32-grade, see
+    include/yolov4_amd.h).  'bf16' (BASELINE configs[4], mixed precision): mode 3 with bf16 operands on the plane layers --
+    one bf16 MFMA per product where the flops are, the fp32-grade HBM-bound kernels elsewhere (y4_set_planes_bf16).
+    2 / 'bf16_all': EVERY conv operand rounded to bf16 (the plane layers on the same bf16 DMA kernels)."""
     from ._lib import check
-    m = {'f32': 0, 'bf16x3': 1, 'bf16': 2, 'f16x2': 3}.get(mode, mode)
+    hybrid = mode == 'bf16'
+    m = {'f32': 0, 'bf16x3': 1, 'bf16_all': 2, 'bf16': 3, 'f16x2': 3}.get(mode, mode)
     check(lib().y4_set_conv_mode(int(m)), 'set_conv_mode')
+    check(lib().y4_set_planes_bf16(1 if hybrid else 0), 'set_planes_bf16')
 
 
 def get_conv_mode():

@@ -892,7 +892,7 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     PlaneWgradGeom g{};
     g.x = static_cast<const unsigned char*>(x); g.dy = static_cast<const unsigned char*>(dy);
     if (stride == 2) {
-        if (k != 3 || (H & 1) || (W & 1) || bf) return Y4_ERR_SHAPE;
+        if (k != 3 || (H & 1) || (W & 1)) return Y4_ERR_SHAPE;
         H /= 2; W /= 2;                                    // from here on: the dy grid
     } else if (stride != 1) return Y4_ERR_SHAPE;
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.pad = (k - 1) / 2;
@@ -919,6 +919,7 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     }
     int rc;
     if (!bf) rc = stride == 2 ? launch_wgrad_planes<128, false, 2>(g, st) : launch_wgrad_planes<128, false>(g, st);
+    else if (stride == 2) rc = tn == 256 ? launch_wgrad_planes<256, true, 2>(g, st) : launch_wgrad_planes<128, true, 2>(g, st);
     else if (tn == 256) rc = launch_wgrad_planes<256, true>(g, st);
     else rc = launch_wgrad_planes<128, true>(g, st);
     if (rc != Y4_OK) return rc;
@@ -943,11 +944,16 @@ int planes_split(const float* x, long long ld, long long M, int C, const unsigne
 }  // namespace y4
 
 // ======================================================================================== C ABI
-// conv mode 3: f16x2 planes (amax words required); conv mode 2: bf16 "planes" (amax words ignored, may be NULL)
+// conv mode 3: f16x2 planes (amax words required); conv mode 2, or mode 3 with y4_set_planes_bf16(1) ("hybrid": bf16 MFMA on
+// the plane layers, fp32-grade f16x2 kernels on the others): bf16 "planes" (amax words ignored, may be NULL)
+static int g_planes_bf16 = 0;
 static inline bool pl_mode_ok() { const int m = y4_get_conv_mode(); return m == 3 || m == 2; }
-static inline bool pl_bf() { return y4_get_conv_mode() == 2; }
+static inline bool pl_bf() { const int m = y4_get_conv_mode(); return m == 2 || (m == 3 && g_planes_bf16); }
 
 extern "C" {
+
+int y4_set_planes_bf16(int on) { g_planes_bf16 = on ? 1 : 0; return Y4_OK; }
+int y4_get_planes_bf16(void) { return g_planes_bf16; }
 
 int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, void* stream) {
     if (!x || !planes || (!amax && !pl_bf())) return Y4_ERR_NULL;
@@ -985,6 +991,8 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
         if (reinterpret_cast<uintptr_t>(dgrad_filter) & 15) return Y4_ERR_SHAPE;
         unsigned* hdr_t = reinterpret_cast<unsigned*>(static_cast<char*>(dgrad_filter) + (size_t)Cin * k * k * Cout * 6);
         // stride 1: mirrored (the plane dgrad is the forward kernel); stride 2: as the register-staged dgrad wants them
+        // (bf16 forward at stride 2: the register-staged dgrad of that layer runs in the conv mode's own arithmetic and splits
+        // the filter itself -- the caller passes no dgrad_filter then)
         if (bf && stride != 1) return Y4_ERR_SHAPE;
         if (bf) rc = bf16_filter(w, planes, static_cast<unsigned short*>(dgrad_filter), Cout, Cin, k * k, true, st);
         else rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin, k * k,

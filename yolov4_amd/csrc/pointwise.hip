@@ -517,7 +517,9 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
                     o[e] = ga[e] * is[e] * (g - k1[e] - xh * k2[e]);
                 }
                 if (bf) {
-                    store_bf16x4(reinterpret_cast<unsigned char*>(dy + m * lddy), c0, o);      // conv mode 2: plain bf16, no scale
+                    // plain bf16, no scale; twin: dy stays fp32 (+ its maximum) for a register-staged dgrad, bf16 to the plane wgrad
+                    store_bf16x4(reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : dy + m * lddy), c0, o);
+                    if (twin) { st4(dy + m * lddy + c0, o); amax_track(amax, o); }
                 } else if (bounds) {
                     // twin: dy stays fp32 for a register-staged dgrad, the pre-split copy (dense rows) goes to the plane wgrad
                     store_planes4(reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : dy + m * lddy), c0, o, ps, paired);
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
             }
         }
     }
-    if (out_amax && !bounds && !bf) amax_commit(amax, out_amax);
+    if (out_amax && !bounds && (!bf || twin)) amax_commit(amax, out_amax);
 }
 
 // generic column sums (C arbitrary, scalar loads): dbias of the 255-channel head convs.  Two fixed-order stages, no atomics:
@@ -922,8 +924,8 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
     const int frozen = flags & 1, bf = (flags >> 1) & 1;
     if (frozen && f16_planes) return Y4_ERR_SHAPE;         // (the plane bound is derived for batch statistics)
-    if (bf && (f16_planes || lddy != C || (C & 31))) return Y4_ERR_SHAPE;
-    if (planes_twin && (!f16_planes || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
+    if (bf && (f16_planes || (!planes_twin && lddy != C) || (C & 31))) return Y4_ERR_SHAPE;
+    if (planes_twin && ((!f16_planes && !bf) || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
     if (!vec_ok(dz, lddz, C) || !vec_ok(y, ldy, C) || !vec_ok(dy, lddy, C) || M <= 0) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_bn_workspace(M, C)) return Y4_ERR_WORKSPACE;
     hipStream_t st = y4_stream(stream);

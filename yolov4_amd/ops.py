@@ -117,7 +117,9 @@ def planes_mode():
     per-tensor scale), 'bf16' (mode 2, BASELINE configs[4]: plain bf16 values in the first half of each fp32-sized pixel row),
     None (the other modes have no DMA-fed kernels)."""
     m = lib().y4_get_conv_mode()
-    return 'f16x2' if m == 3 else ('bf16' if m == 2 else None)
+    if m == 2 or (m == 3 and lib().y4_get_planes_bf16()):
+        return 'bf16'                                # (mode 3 + the switch: only the plane layers compute in bf16)
+    return 'f16x2' if m == 3 else None
 
 
 def new_amax(device, n=1):
@@ -231,7 +233,9 @@ def fast_conv_shape(Cin, k, s):
 
 def planes_stride2_ok(k, s, H, W):
     """The 3x3 stride-2 layers run on the plane kernels (forward; wgrad with x read at 4 p - 2 w) on even maps, f16x2 only."""
-    return s == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and planes_mode() == 'f16x2' and _S2_PLANES
+    # (bf16 operands: only in the hybrid mode, whose register-staged stride-2 dgrad is the f16x2 one; mode 2 keeps stride 2 off planes)
+    return (s == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and _S2_PLANES
+            and (planes_mode() == 'f16x2' or (planes_mode() == 'bf16' and f16x2_mode())))
 
 
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
@@ -814,7 +818,8 @@ class ConvBNActFn(torch.autograd.Function):
             # the backward pass wants the transposed planes of the same filter: the forward split launch writes both
             ctx.dgrad_filter = None
             if ((f16 or (bfm and xp is not None)) and ctx.needs_input_grad[0] and x.shape[1] % 32 == 0 and fast_conv_shape(x.shape[1], k, s)
-                    and weight.shape[0] % 4 == 0 and (xp is None or weight.shape[0] % 32 == 0)):
+                    and weight.shape[0] % 4 == 0 and (xp is None or weight.shape[0] % 32 == 0)
+                    and not (bfm and xp is not None and s == 2)):    # (bf16 planes at stride 2: the f16x2 dgrad splits the filter itself)
                 ctx.dgrad_filter = dgrad_filter_buffer(x.shape[1], weight.shape[0], k, x.device)
             if xp is not None:
                 y, mean, invstd = conv_fwd_planes_bnstats_raw(xp, weight, k, s, cfg['running_mean'], cfg['running_var'],
