@@ -152,7 +152,11 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
                              void* dgrad_filter /* nullable: as in y4_conv2d_fwd_bnstats_f32 -- stride 1: for
                                 y4_conv2d_dgrad_planes_f32 (mirrored taps); stride 2: for y4_conv2d_dgrad_f32 (the register-staged
                                 parity-class dgrad, taps as they are) */,
-                             size_t dgrad_filter_bytes, void* stream);
+                             size_t dgrad_filter_bytes,
+                             int y_bf16 /* != 0 (Cout % 32 == 0): y leaves as plain bf16 (RN) in the FIRST HALF of each fp32-sized row
+                                (pitch 4 ldy bytes), the column sums are those of the rounded values; the BatchNorm sweeps read it
+                                with y4_bn_act_fwd_f32 z_planes + 16 / y4_bn_act_bwd_f32 frozen_stats bit 2 */,
+                             void* stream);
 
 /* dgrad (stride 1) / wgrad (stride 1, and the 3x3 stride-2 layers on even maps) of a conv over planes (dy, and for wgrad also
  * x, pre-split as above; Cin % 32 == 0, Cout % 32 == 0): the same arithmetic as y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 in
@@ -250,6 +254,7 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
  * for any sample of M values, |act(v)| <= |v|, so |z| <= max_c(|gamma_c| sqrt(M - 1) + |beta_c|) + max|residual|
  * (res_amax: the residual's maximum word, required with a residual) -- and leaves it in *out_amax for the consumers.  A
  * loose bound costs the split only headroom (full precision down to 2^-29 of the bound).
+ * z_planes + 16: y itself holds plain bf16 values in the first half of each row (y4_conv2d_fwd_planes_f32 y_bf16).
  * z_planes == 3 (conv mode 2, bf16 MFMA conv): z receives plain bf16 values (RN), dense per pixel in the FIRST HALF of the
  * fp32-sized row (ldz == C: the row pitch stays 4 C bytes, the second half is not touched); out_amax is not used.
  * planes_twin (nullable, with z_planes != 0): z stays fp32 (pitch ldz) and planes_twin [M][C] receives the pre-split copy --
@@ -275,6 +280,7 @@ int y4_bn_act_bwd_f32(const float* dz, int lddz, const float* y, int ldy,
                          not (3x3 stride 2) */,
                       int frozen_stats /* bit 0: mean / invstd are constants (eval-mode BatchNorm under autograd: running
                          statistics), so dy = gamma invstd g without the two batch-statistic terms; dgamma / dbeta as usual.
+                         bit 2: y holds plain bf16 values in the first half of each row (as y4_bn_act_fwd_f32 z_planes + 16).
                          bit 1 (conv mode 2): dy leaves as plain bf16 in the first half of each fp32-sized row, as
                          y4_bn_act_fwd_f32 z_planes == 3 (lddy == C, C % 32 == 0, f16_planes NULL) */,
                       void* stream);

@@ -468,3 +468,52 @@ def test_hybrid_bf16_mode_runs_plane_layers_in_bf16_and_the_others_fp32_grade(de
         assert bool(torch.isfinite(v1).all())
         top = max(float(v0.abs().max()), 1e-6)
         assert float((v1 - v0).abs().mean()) <= 2e-2 * top and float((v1 - v0).abs().max()) <= 0.15 * top
+
+
+def _bf16_payload(y):
+    """the bf16 values a y_bf16 conv result carries in the first half of each pixel row, as fp32 [B, C, H, W]"""
+    B, C, H, W = y.shape
+    rows = y.permute(0, 2, 3, 1).contiguous().view(torch.int16)          # [B, H, W, 2 C] 16-bit words
+    return rows[..., :C].contiguous().view(torch.bfloat16).float().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 128, 3, 1, 9, 9), (3, 256, 512, 3, 1, 19, 19), (2, 128, 256, 3, 2, 20, 12), (5, 512, 256, 1, 1, 7, 7),
+                                  (2, 64, 192, 1, 1, 20, 20)])
+def test_bf16_conv_result_and_batchnorm_sweeps_over_it(dev, bf16_mode, case):
+    """conv mode 'bf16': the plane conv may leave its result y as bf16 (y_bf16; half the bytes for the three BatchNorm sweeps
+    that read it).  (1) the stored values are the fp32 results rounded to nearest-even bf16, the epilogue's column sums are
+    those of the ROUNDED values; (2) BatchNorm forward / backward over the bf16 y are bit-identical to the same sweeps over an
+    fp32 tensor holding the same values."""
+    from yolov4_amd import ops
+    B, ci, co, k, s, H, W = case
+    x = recipe.randn((B, ci, H, W), 7)
+    w = recipe.randn((co, ci, k, k), 8, 1.0 / np.sqrt(ci * k * k))
+    xp = ops.planes_split_raw(cl(x, dev))
+    wd = cl(w, dev)
+    y32 = ops.conv_fwd_planes_raw(xp, wd, k, s, stats=False)
+    yb, part, n = ops.conv_fwd_planes_raw(xp, wd, k, s, y_bf16=True)
+    torch.cuda.synchronize()
+    assert 'true, true>' in ops.last_conv_kernel(), ops.last_conv_kernel()
+    got = _bf16_payload(yb)
+    assert torch.equal(got, y32.bfloat16().float())                         # RN-even of the very same accumulators
+    st = part.view(torch.float32)[:n * 2 * co].view(n, 2, co).double().sum(0).cpu()
+    gf = got.double().cpu().permute(0, 2, 3, 1).reshape(-1, co)
+    assert float((st[0] - gf.sum(0)).abs().max()) <= 1e-5 * max(float(gf.abs().sum(0).max()), 1e-6)
+    assert float((st[1] - (gf * gf).sum(0)).abs().max()) <= 1e-5 * float((gf * gf).sum(0).max())
+    # ---- BatchNorm sweeps: bf16 y vs an fp32 tensor with the same values
+    yf = got.to(dev).contiguous(memory_format=torch.channels_last)
+    Bo, _, Ho, Wo = yf.shape
+    mean = yf.mean(dim=(0, 2, 3)).contiguous()
+    invstd = (1.0 / torch.sqrt(yf.var(dim=(0, 2, 3), unbiased=False) + 1e-5)).contiguous()
+    gamma = torch.rand(co, device=dev) + 0.5
+    beta = torch.randn(co, device=dev) * 0.1
+    for planes in (False, True):
+        za = ops.bn_act_fwd_raw(yb, mean, invstd, gamma, beta, 'mish', planes=planes, y_bf16=True)
+        zb = ops.bn_act_fwd_raw(yf, mean, invstd, gamma, beta, 'mish', planes=planes)
+        assert torch.equal(za.view(torch.int32) if not planes else torch.Tensor.view(za.as_subclass(torch.Tensor), torch.int32),
+                           zb.view(torch.int32) if not planes else torch.Tensor.view(zb.as_subclass(torch.Tensor), torch.int32))
+    dz = cl(recipe.randn((Bo, co, Ho, Wo), 11), dev)
+    da = ops.bn_act_bwd_raw(dz, yb, mean, invstd, gamma, beta, 'mish', y_bf16=True)
+    db = ops.bn_act_bwd_raw(dz, yf, mean, invstd, gamma, beta, 'mish')
+    for a, b in zip(da, db):
+        assert torch.equal(a, b)

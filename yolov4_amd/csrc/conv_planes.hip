@@ -44,6 +44,7 @@ struct PlaneConvGeom {
     float* dst; long long ldd;         // raw fp32 result [M][ldd]
     const float* res; long long ldr;   // optional: added in the epilogue (dgrad: gradient arriving over a skip connection)
     float* stats;                      // optional: per-M-tile column sums [mtiles][2][N] of the result
+    int dst_bf16;                      // the result leaves as bf16 (RN) in the first half of each fp32-sized row (pitch 4 ldd bytes)
     int B, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad, M, K;
     int mtiles, ntiles;
     unsigned long long src_total_bytes;
@@ -72,7 +73,9 @@ __device__ __forceinline__ f32x4v pl_mma(const f16x8 a, const f16x8 b, const f32
     else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, bool BF>
+// YB (with BF): the result leaves as bf16 (PlaneConvGeom::dst_bf16) -- a variant of its own, so that the three store forms of
+// the epilogue do not share one register allocation (as run-time branches they cost the 128 x 64 wave tile 14 spills)
+template <int BM, int BN, int WM, int WN, bool BF, bool YB = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_planes_mfma(const PlaneConvGeom g) {
     constexpr int NWAVE = WM * WN, NTHR = NWAVE * 64;
     static_assert(NWAVE == 8 || NWAVE == 4, "8 or 4 waves");
@@ -303,33 +306,43 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
         const __amdgpu_buffer_rsrc_t drs = y4_make_rsrc(reinterpret_cast<char*>(g.dst) + row0 * (long long)drow, (unsigned)(dby < 0xfffffff0ull ? dby : 0xfffffff0ull));
         const __amdgpu_buffer_rsrc_t rrs = y4_make_rsrc(g.res ? reinterpret_cast<const char*>(g.res) + row0 * (long long)rrow : nullptr,
                                                         g.res ? (unsigned)(rby < 0xfffffff0ull ? rby : 0xfffffff0ull) : 0u);
+        // the epilogue's lane arithmetic starts from an opaque copy of the lane id: otherwise the compiler forms the addresses of
+        // all three store variants before the K loop, where the registers are taken (256 x 256 bf16 shape: 14 spilled)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int fr = lane_e & 15, kq = lane_e >> 4;
         const int colb = n0 + wn * WTN + fr;
         const bool allc = n0 + BN <= g.N;
+        if constexpr (!YB) {
         if (g.res) {
             // skip operand (dgrad: the gradient arriving over a ResBlock skip connection): the 4 x TN loads of a row tile all go
             // out before the first of them is needed -- issued one by one in front of their stores, each store waited for
             // its own dependent load (128->128 1x1 @76^2 dgrad ran at half its forward rate)
+            constexpr int EB = TM > 4 ? 1 : 4;             // accumulator rows per batch of loads (the 128 x 64 wave tile has 16 fewer registers to spare)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const unsigned rl = (unsigned)(wm * WTM + 16 * i + 4 * kq);
                 const unsigned dvo = rl * drow + (unsigned)colb * 4u, rvo = rl * rrow + (unsigned)colb * 4u;
-                float rv[4][TN];
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e0 = 0; e0 < 4; e0 += EB) {
+                    float rv[EB][TN];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const bool cok = allc || colb + 16 * j < g.N;
-                        rv[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(cok ? rvo + 64u * j : 0xffffffffu), (int)(e * rrow), 0));
-                    }
+                    for (int e = 0; e < EB; ++e)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                        for (int j = 0; j < TN; ++j) {
+                            const bool cok = allc || colb + 16 * j < g.N;
+                            rv[e][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)(cok ? rvo + 64u * j : 0xffffffffu), (int)((e0 + e) * rrow), 0));
+                        }
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const float v = result(i, j, e);
-                        acc0[i][j][e] = v;                 // kept for the column sums
-                        const bool cok = allc || colb + 16 * j < g.N;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rv[e][j]), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
-                    }
+                    for (int e = 0; e < EB; ++e)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float v = result(i, j, e0 + e);
+                            acc0[i][j][e0 + e] = v;        // kept for the column sums
+                            const bool cok = allc || colb + 16 * j < g.N;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rv[e][j]), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)((e0 + e) * drow), 0);
+                        }
+                }
             }
         } else {
 #pragma unroll
@@ -347,6 +360,37 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                     }
             }
         }
+        } else {
+            // bf16 result (conv mode 'bf16': what the BatchNorm sweeps then read is half the bytes): rounded to nearest even,
+            // the column sums are taken over the ROUNDED values (they normalise what is stored); lanes 2k / 2k + 1 hold adjacent
+            // columns: the even lane packs both and stores one dword (N is a multiple of 32 on this path: pairs are whole)
+            // (the column sums are formed right here, row tile by row tile, and parked in acc0[0][j][0..1] for the block fold below:
+            // a second pass over 128 live accumulators cost the 128 x 64 wave tile a spill)
+            float csum[TN], cssum[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { csum[j] = 0.f; cssum[j] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned rl = (unsigned)(wm * WTM + 16 * i + 4 * kq);
+                const unsigned dvo = rl * drow + (unsigned)colb * 2u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float v = result(i, j, e);
+                        unsigned u = __builtin_bit_cast(unsigned, v);
+                        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;          // RN-even to bf16 (finite values)
+                        const float vr = __builtin_bit_cast(float, u);
+                        csum[j] += vr; cssum[j] += vr * vr;
+                        const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, true);   // lane ^ 1
+                        const bool cok = (allc || colb + 16 * j < g.N) && !(fr & 1);
+                        __builtin_amdgcn_raw_buffer_store_b32((u >> 16) | nb, drs, (int)(cok ? dvo + 32u * j : 0xffffffffu), (int)(e * drow), 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);         // (one row tile at a time)
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { acc0[0][j][0] = csum[j]; acc0[0][j][1] = cssum[j]; }
+        }
     }
     if (g.stats) {                                         // rows past M are exact zeros (their operand rows were zero-filled)
         __syncthreads();                                   // every wave has left the last stage
@@ -354,10 +398,14 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float cs = 0.f, css = 0.f;
+            if constexpr (YB) {
+                cs = acc0[0][j][0]; css = acc0[0][j][1];   // (summed in the store loop)
+            } else {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float v = acc0[i][j][e]; cs += v; css += v * v; }
+                    for (int e = 0; e < 4; ++e) { const float v = acc0[i][j][e]; cs += v; css += v * v; }
+            }
             cs += __shfl_xor(cs, 16, 64); css += __shfl_xor(css, 16, 64);
             cs += __shfl_xor(cs, 32, 64); css += __shfl_xor(css, 32, 64);
             if (kq == 0) {
@@ -756,7 +804,7 @@ int bf16_filter(const float* w, unsigned short* fwd, unsigned short* tr, int Cou
     return Y4_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool BF>
+template <int BM, int BN, int WM, int WN, bool BF, bool YB = false>
 int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     PlaneConvGeom g = g0;
     g.mtiles = (g.M + BM - 1) / BM;
@@ -766,11 +814,10 @@ int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     constexpr size_t smem = ((NW == 8 && 3 * stage <= 160 * 1024) ? 3ull : 2ull) * stage;   // the stages; the epilogue needs WM * BN * 8 B of them
     static_assert(NW == 8 || 2 * smem <= 160 * 1024, "two blocks per CU");
     static_assert(smem <= 160 * 1024, "LDS");
-    auto kern = conv_planes_mfma<BM, BN, WM, WN, BF>;
+    auto kern = conv_planes_mfma<BM, BN, WM, WN, BF, YB>;
     static Y4DynLds lds_attr;                              // per device, see common.h
     if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
-    if (BF) y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d, true>", BM, BN, WM, WN);
-    else y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d, false>", BM, BN, WM, WN);
+    y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d, %s, %s>", BM, BN, WM, WN, BF ? "true" : "false", YB ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -788,8 +835,10 @@ bool planes_conv_ok(int Cin, int Cout, int k, int stride) {
 // optional per-M-tile column sums (256-row tiles).  bf: plain bf16 operands (conv mode 2), amax words unused.
 int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,
                 const float* res, long long ldr, float* stats, int* nparts, int B, int Hs, int Ws, int Cs, int N, int k, int stride,
-                hipStream_t st, bool bf) {
+                hipStream_t st, bool bf, bool dst_bf16) {
     PlaneConvGeom g{};
+    if (dst_bf16 && (res || (N & 31))) return Y4_ERR_SHAPE;
+    g.dst_bf16 = dst_bf16 ? 1 : 0;
     const int pad = (k - 1) / 2;
     g.src = static_cast<const unsigned char*>(src); g.wt = static_cast<const unsigned char*>(wt_planes);
     g.dst = dst; g.ldd = ldd; g.res = res; g.ldr = ldr; g.stats = stats;
@@ -833,11 +882,13 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
         const bool big = bf_tile == 2 || (bf_tile == 0 && N > 128 && (double)r256 * 2.0 <= (double)r128 * 1.25);
         if (small && !big) {
             if (nparts) *nparts = (g.M + 127) / 128;
-            return launch_conv_planes<128, 128, 2, 2, true>(g, st);
+            return dst_bf16 ? launch_conv_planes<128, 128, 2, 2, true, true>(g, st) : launch_conv_planes<128, 128, 2, 2, true>(g, st);
         }
         if (nparts) *nparts = (g.M + 255) / 256;
+        if (dst_bf16) return big ? launch_conv_planes<256, 256, 2, 4, true, true>(g, st) : launch_conv_planes<256, 128, 4, 2, true, true>(g, st);
         return big ? launch_conv_planes<256, 256, 2, 4, true>(g, st) : launch_conv_planes<256, 128, 4, 2, true>(g, st);
     }
+    if (dst_bf16) return Y4_ERR_SHAPE;                     // (bf16 results: the bf16 operand kernels only)
     if (nparts) *nparts = small ? (g.M + 127) / 128 : (g.M + 255) / 256;
     return small ? launch_conv_planes<128, 128, 2, 2, false>(g, st) : launch_conv_planes<256, 128, 4, 2, false>(g, st);
 }
@@ -967,7 +1018,7 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
                              int B, int H, int W, int Cin, int Cout, int k, int stride,
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
                              void* workspace, size_t workspace_bytes, void* dgrad_filter, size_t dgrad_filter_bytes,
-                             void* stream) {
+                             int y_bf16, void* stream) {
     if (!x_planes || !w || !y || !workspace) return Y4_ERR_NULL;
     if (!pl_mode_ok()) return Y4_ERR_SHAPE;
     const bool bf = pl_bf();
@@ -1003,7 +1054,7 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
     }
     if (rc != Y4_OK) return rc;
     int np = 0;
-    rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, nullptr, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st, bf);
+    rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, nullptr, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st, bf, y_bf16 != 0);
     if (nparts_host) *nparts_host = np;
     return rc;
 }

@@ -29,6 +29,17 @@ static inline RowMap row_map(int C) {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// four channels c0 .. c0 + 3 of the row starting at `row` (a float pointer: pitch in fp32 elements); ybf: the row holds plain
+// bf16 values in its FIRST HALF (conv mode 'bf16': the plane conv kernels write their result that way, conv_planes.hip)
+__device__ __forceinline__ f32x4 ld4y(const float* row, int c0, int ybf) {
+    if (!ybf) return ld4(row + c0);
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 b = *reinterpret_cast<const u2*>(reinterpret_cast<const unsigned char*>(row) + c0 * 2);
+    f32x4 v;
+    v[0] = __uint_as_float(b[0] << 16); v[1] = __uint_as_float(b[0] & 0xffff0000u);
+    v[2] = __uint_as_float(b[1] << 16); v[3] = __uint_as_float(b[1] & 0xffff0000u);
+    return v;
+}
 
 // ---------------------------------------------------------------- BN statistics
 // Each thread sums <= ROWS_PER_THREAD rows in fp32, the block folds row groups through LDS and
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const float* __restrict__ res, long long ldr, float* __restrict__ z, long long ldz,
-    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, int planes, float* __restrict__ twin) {
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, int planes, float* __restrict__ twin, int ybf) {
     // planes = 0: z fp32, max|z| folded into *out_amax.  z == nullptr: measure only (max|z| into *out_amax, nothing stored).
     // planes = 1: z receives the two fp16 pieces of the f16x2 split, per pixel and 32-channel K tile [64 B hi | 64 B lo]
     //             (conv_planes.hip), scaled by the power of two that *out_amax -- a bound or a measured maximum -- implies.
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
                 const long long m = ((t0 * gridDim.x + blockIdx.x) * PW_UNROLL + u) * rpb + rg;
                 mm[u] = m < M ? m : -1;
                 const long long ml = mm[u] < 0 ? 0 : mm[u];
-                v[u] = ld4(y + ml * ldy + c0);
+                v[u] = ld4y(y + ml * ldy, c0, ybf);
                 if (res) r[u] = ld4(res + ml * ldr + c0);
             }
 #pragma unroll
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dz, long long lddz, const float* __restrict__ y, long long ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
-    long long M, int C, int tpr, int rpb, int nrows, float* __restrict__ part, unsigned* __restrict__ bounds) {
+    long long M, int C, int tpr, int rpb, int nrows, float* __restrict__ part, unsigned* __restrict__ bounds, int ybf) {
     __shared__ float red[2][PW_THREADS][4];
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
@@ -369,7 +380,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
                 const long long m = row_of(i + u);
                 ok[u] = m < M && cok;
                 const long long mm = m < M ? m : M - 1;
-                v[u] = ld4(y + mm * ldy + cs);
+                v[u] = ld4y(y + mm * ldy, cs, ybf);
                 d[u] = ld4(dz + mm * lddz + cs);
             }
 #pragma unroll
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
         for (; i < nrows; ++i) {
             const long long m = row_of(i);
             if (m < M && cok) {
-                const f32x4 v = ld4(y + m * ldy + c0);
+                const f32x4 v = ld4y(y + m * ldy, c0, ybf);
                 const f32x4 d = ld4(dz + m * lddz + c0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
     const double* __restrict__ acc, float* __restrict__ dy, long long lddy,
     long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, unsigned* __restrict__ bounds, int frozen, int bf,
-    float* __restrict__ twin) {
+    float* __restrict__ twin, int ybf) {
     const int tid = threadIdx.x;
     const int cv = tid % tpr, rg = tid / tpr;
     const double invM = frozen ? 0.0 : 1.0 / (double)M;    // frozen statistics: no batch-statistic terms in dy
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
                 const long long m = ((t0 * gridDim.x + blockIdx.x) * PW_UNROLL + u) * rpb + rg;
                 mm[u] = m < M ? m : -1;
                 const long long ml = mm[u] < 0 ? 0 : mm[u];
-                v[u] = ld4(y + ml * ldy + c0);
+                v[u] = ld4y(y + ml * ldy, c0, ybf);
                 d[u] = ld4(dz + ml * lddz + c0);
             }
 #pragma unroll
@@ -893,6 +904,8 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
                       long long M, int C, unsigned* out_amax, int z_planes, const unsigned* res_amax, float* planes_twin,
                       void* stream) {
     if (!y || !mean || !invstd || !gamma || !beta) return Y4_ERR_NULL;
+    const int ybf = (z_planes >> 4) & 1;                                         // + 16: y holds bf16 values (first half of each row)
+    z_planes &= 15;
     if (!z && (!out_amax || z_planes)) return Y4_ERR_NULL;                       // measure-only needs the word to fill
     if (z_planes < 0 || z_planes > 3) return Y4_ERR_SHAPE;
     if (planes_twin && (!z_planes || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
@@ -911,7 +924,7 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
                        (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
-                       M, C, rm.tpr, rm.rpb, z_planes == 3 ? nullptr : out_amax, z_planes == 3 ? 2 : (z_planes ? 1 : 0), planes_twin);
+                       M, C, rm.tpr, rm.rpb, z_planes == 3 ? nullptr : out_amax, z_planes == 3 ? 2 : (z_planes ? 1 : 0), planes_twin, ybf);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -922,7 +935,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
                            long long M, int C, void* workspace, size_t workspace_bytes, unsigned* out_amax,
                            unsigned* f16_planes, float* planes_twin, int flags, void* stream) {
     if (!dz || !y || !mean || !invstd || !gamma || !beta || !dy || !dgamma || !dbeta || !workspace) return Y4_ERR_NULL;
-    const int frozen = flags & 1, bf = (flags >> 1) & 1;
+    const int frozen = flags & 1, bf = (flags >> 1) & 1, ybf = (flags >> 2) & 1;
     if (frozen && f16_planes) return Y4_ERR_SHAPE;         // (the plane bound is derived for batch statistics)
     if (bf && (f16_planes || (!planes_twin && lddy != C) || (C & 31))) return Y4_ERR_SHAPE;
     if (planes_twin && ((!f16_planes && !bf) || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
@@ -938,7 +951,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     int nb = 0;
     {
         hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3((unsigned)rblocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz,
-                           y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, nrows, part, f16_planes);
+                           y, (long long)ldy, mean, invstd, gamma, beta, act, M, C, rm.tpr, rm.rpb, nrows, part, f16_planes, ybf);
         Y4_CHECK_LAUNCH();
         const int rc = fold_partials(part, rblocks, C, bacc, &nb, st);
         if (rc != Y4_OK) return rc;
@@ -951,7 +964,7 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
                        (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,
-                       out_amax, f16_planes, frozen ? 1 : 0, bf, planes_twin);
+                       out_amax, f16_planes, frozen ? 1 : 0, bf, planes_twin, ybf);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }

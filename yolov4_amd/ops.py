@@ -239,6 +239,7 @@ def planes_stride2_ok(k, s, H, W):
 
 
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
+_BF16_Y = os.environ.get('Y4_BF16_Y', '1') != '0'            # (A/B switch: bf16 conv results on the plane layers of conv mode 'bf16')
 
 
 def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
@@ -407,8 +408,9 @@ def planes_split_raw(x, amax=None):
     return Planes(buf, (B, C, H, W), amax)
 
 
-def conv_fwd_planes_raw(xp, w, k, s, stats=True, dgrad_filter=None):
-    """Training-mode conv over a Planes input: raw output y (+ per-M-tile column sums, n_tiles)."""
+def conv_fwd_planes_raw(xp, w, k, s, stats=True, dgrad_filter=None, y_bf16=False):
+    """Training-mode conv over a Planes input: raw output y (+ per-M-tile column sums, n_tiles).  y_bf16: y leaves as plain
+    bf16 in the first half of each row of the (float32-typed) result -- an internal tensor only the BatchNorm sweeps read."""
     L = lib()
     B, Cin, H, W = xp.shape
     Cout = w.shape[0]
@@ -422,15 +424,16 @@ def conv_fwd_planes_raw(xp, w, k, s, stats=True, dgrad_filter=None):
     n = ctypes.c_longlong(0)
     check(L.y4_conv2d_fwd_planes_f32(_ptr(xp.buf), _ptr(w), _ptr(y), nhwc_pitch(y), B, H, W, Cin, Cout, k, s,
                                      _ptr(part), pbytes, ctypes.byref(n), _ptr(xp.amax), _ptr(ws), nbytes,
-                                     _ptr(dgrad_filter), dgrad_filter.numel() if dgrad_filter is not None else 0, _stream()),
+                                     _ptr(dgrad_filter), dgrad_filter.numel() if dgrad_filter is not None else 0,
+                                     1 if y_bf16 else 0, _stream()),
           'conv2d_fwd_planes')
     return (y, part, n.value) if stats else y
 
 
-def conv_fwd_planes_bnstats_raw(xp, w, k, s, running_mean, running_var, nbt, momentum, eps, dgrad_filter=None):
+def conv_fwd_planes_bnstats_raw(xp, w, k, s, running_mean, running_var, nbt, momentum, eps, dgrad_filter=None, y_bf16=False):
     """conv_fwd_bnstats_raw over a Planes input: (y, mean, invstd)."""
     L = lib()
-    y, part, nparts = conv_fwd_planes_raw(xp, w, k, s, dgrad_filter=dgrad_filter)
+    y, part, nparts = conv_fwd_planes_raw(xp, w, k, s, dgrad_filter=dgrad_filter, y_bf16=y_bf16)
     Cout = w.shape[0]
     M = y.shape[0] * y.shape[2] * y.shape[3]
     mean = torch.empty(Cout, device=y.device, dtype=torch.float32)
@@ -603,7 +606,7 @@ def _slot_ok(out, shape):
             and out.data_ptr() % 16 == 0)
 
 
-def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None, planes=False):
+def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None, planes=False, y_bf16=False):
     """planes: z leaves PRE-SPLIT for the plane conv kernels (a float32-typed tensor whose 4 bytes per element hold the two
     fp16 pieces; tagged y4_planes), scaled by an analytic bound of max|z| that the call leaves in the tensor's cell (no
     measuring pass; with a residual whose maximum is unknown: one measure-only launch first)."""
@@ -613,13 +616,14 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
     ldr = 0
     if residual is not None:
         residual, ldr = as_nhwc(residual)
+    yb = 16 if y_bf16 else 0                         # y holds bf16 values (conv_fwd_planes_raw y_bf16)
     if planes:
         both = planes == 'both'
         zp = empty_nhwc(B, C, H, W, y.device)        # the pre-split tensor (float32-typed, 4 bytes per element)
         z = (out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)) if both else zp
         args = (_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act], _ptr(residual), ldr)
         if planes_mode() == 'bf16':                  # conv mode 2: plain bf16 values in the first half of each row, no scale
-            check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, None, 3, None,
+            check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, None, 3 + yb, None,
                                       _ptr(zp) if both else None, _stream()), 'bn_act_fwd(bf16)')
             zp = as_planes(zp)
             if both:
@@ -629,11 +633,11 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
         cell = planes_cell(y.device)
         res_cell = amax_of(residual) if residual is not None else None
         if residual is not None and res_cell is None:
-            check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), 0, None, None, _stream()), 'bn_act_fwd(measure)')
+            check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), yb, None, None, _stream()), 'bn_act_fwd(measure)')
             mode = 1
         else:
             mode = 2
-        check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), mode, _ptr(res_cell),
+        check(L.y4_bn_act_fwd_f32(*args, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(cell), mode + yb, _ptr(res_cell),
                                   _ptr(zp) if both else None, _stream()), 'bn_act_fwd(planes)')
         zp = as_planes(zp, cell)
         if both:
@@ -642,13 +646,13 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
         return as_planes(zp, cell[0:1])
     z = out if _slot_ok(out, (B, C, H, W)) else empty_nhwc(B, C, H, W, y.device)
     check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act],
-                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), 0, None, None, _stream()),
+                              _ptr(residual), ldr, _ptr(z), nhwc_pitch(z), B * H * W, C, _ptr(out_amax), yb, None, None, _stream()),
           'bn_act_fwd')
     return z
 
 
 def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta_out=None, out_amax=None, planes=None,
-                   frozen=False, bf16=False, twin=False):
+                   frozen=False, bf16=False, twin=False, y_bf16=False):
     """dgamma_out / dbeta_out: optional contiguous fp32 [C] destinations (gradient slots of a flat DDP bucket).
     twin (with planes): dy stays fp32 and the pre-split copy is returned beside it: (dy, dgamma, dbeta, dy_planes)."""
     L = lib()
@@ -667,7 +671,7 @@ def bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act, dgamma_out=None, dbeta
     check(L.y4_bn_act_bwd_f32(_ptr(dz), lddz, _ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta),
                               ACT_IDS[act], _ptr(dy), nhwc_pitch(dy), _ptr(dgamma), _ptr(dbeta), B * H * W, C,
                               _ptr(ws), nbytes, _ptr(out_amax), _ptr(planes), _ptr(dyp) if twin else None,
-                              (1 if frozen else 0) | (2 if bf16 else 0), _stream()),
+                              (1 if frozen else 0) | (2 if bf16 else 0) | (4 if y_bf16 else 0), _stream()),
           'bn_act_bwd')
     if twin:
         return dy, dgamma, dbeta, dyp
@@ -821,9 +825,12 @@ class ConvBNActFn(torch.autograd.Function):
                     and weight.shape[0] % 4 == 0 and (xp is None or weight.shape[0] % 32 == 0)
                     and not (bfm and xp is not None and s == 2)):    # (bf16 planes at stride 2: the f16x2 dgrad splits the filter itself)
                 ctx.dgrad_filter = dgrad_filter_buffer(x.shape[1], weight.shape[0], k, x.device)
+            # conv mode 'bf16': the plane conv writes y as bf16 (half the bytes for the three BatchNorm sweeps that read it)
+            ybf = ctx.y_bf16 = bool(bfm and xp is not None and weight.shape[0] % 32 == 0 and _BF16_Y)
             if xp is not None:
                 y, mean, invstd = conv_fwd_planes_bnstats_raw(xp, weight, k, s, cfg['running_mean'], cfg['running_var'],
-                                                              cfg['nbt'], cfg['momentum'], cfg['eps'], dgrad_filter=ctx.dgrad_filter)
+                                                              cfg['nbt'], cfg['momentum'], cfg['eps'], dgrad_filter=ctx.dgrad_filter,
+                                                              y_bf16=ybf)
             else:
                 y, mean, invstd = conv_fwd_bnstats_raw(x, weight, k, s, cfg['running_mean'], cfg['running_var'],
                                                        cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax,
@@ -831,7 +838,7 @@ class ConvBNActFn(torch.autograd.Function):
             want = cfg.get('out_planes')
             if want and (f16 or bfm) and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
                 z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest if want == 'both' else None,
-                                   planes='both' if want == 'both' else True)
+                                   planes='both' if want == 'both' else True, y_bf16=ybf)
                 z_amax = getattr(z, 'y4_amax', None)
                 if io is not None:
                     io['z_planes'] = want != 'both'
@@ -841,7 +848,7 @@ class ConvBNActFn(torch.autograd.Function):
                     z_amax = live(cfg.get('out_amax')) if (dest is not None and _slot_ok(dest, tuple(y.shape))) else None
                     if z_amax is None:
                         z_amax = new_amax(x.device)
-                z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax)
+                z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, out_amax=z_amax, y_bf16=ybf)
             ctx.save_for_backward(xp.buf if xp is not None else x, weight, y, mean, invstd, gamma, beta)
             ctx.mode = 'bn_train'
         elif bn and cfg.get('grad', True) and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4)):
@@ -916,7 +923,7 @@ class ConvBNActFn(torch.autograd.Function):
             res = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                  gp.grad if sink else None, bp.grad if sink else None,
                                  out_amax=None if planes is not None else dy_amax, planes=planes,
-                                 frozen=ctx.mode == 'bn_eval_grad', bf16=bfp, twin=twin_dy)
+                                 frozen=ctx.mode == 'bn_eval_grad', bf16=bfp, twin=twin_dy, y_bf16=getattr(ctx, 'y_bf16', False))
             dy, dgamma, dbeta = res[:3]
             dy_pl = res[3] if twin_dy else dy
             if sink and dgamma is gp.grad and dbeta is bp.grad:
