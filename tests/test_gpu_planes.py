@@ -262,7 +262,7 @@ def test_bf16_planes_forward_dgrad_wgrad_are_exact_bf16_products(dev, bf16_mode,
     assert xp.amax is None
     y, part, n = ops.conv_fwd_planes_raw(xp, wd, k, s)
     torch.cuda.synchronize()
-    assert 'true>' in ops.last_conv_kernel(), ops.last_conv_kernel()
+    assert ', true, ' in ops.last_conv_kernel(), ops.last_conv_kernel()
     err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
     # column sums of the epilogue = sums of the stored result
@@ -462,7 +462,7 @@ def test_hybrid_bf16_mode_runs_plane_layers_in_bf16_and_the_others_fp32_grade(de
         o0, gx0, gp0 = run()
     finally:
         yolov4_amd.set_conv_mode(old)
-    assert 'f16x2' in names[0] and 'true>' in names[1], names        # fp32-grade kernel for the 32-channel layer, bf16 planes for the 3x3
+    assert 'f16x2' in names[0] and ', true, ' in names[1], names        # fp32-grade kernel for the 32-channel layer, bf16 planes for the 3x3
     assert 'false' in names[3], names
     for v1, v0 in [(o1, o0), (gx1, gx0)] + list(zip(gp1, gp0)):
         assert bool(torch.isfinite(v1).all())
