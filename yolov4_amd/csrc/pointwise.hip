@@ -3,7 +3,6 @@
 // pools, nearest x2 upsample.  All NHWC fp32 with an explicit pixel pitch, 16-B vector access
 // (C % 4 == 0, pitch % 4 == 0, 16-B aligned bases), one channel-vector per thread so the
 // per-channel constants live in registers for the whole row sweep.
-#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -282,7 +281,6 @@ __device__ __forceinline__ void store_bf16x4(unsigned char* row_base, int c0, co
 }
 
 // ---------------------------------------------------------------- BN apply + act (+ skip)
-template <int UN>
 __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ gamma, const float* __restrict__ beta, int act,
@@ -313,22 +311,22 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
             a[e] = invstd[c0 + e] * gamma[c0 + e];
             b[e] = beta[c0 + e] - mean[c0 + e] * a[e];
         }
-        // UN row groups per trip, every load issued before the first use, and the block's rows of a trip CONTIGUOUS:
+        // PW_UNROLL row groups per trip, every load issued before the first use, and the block's rows of a trip CONTIGUOUS:
         // all blocks together advance one front through the tensor (rows of a trip spread gridDim apart: 10 % slower, measured)
         const long long stride = (long long)gridDim.x * rpb;
-        for (long long t0 = 0; t0 * stride * UN < M; ++t0) {
-            f32x4 v[UN], r[UN];
-            long long mm[UN];
+        for (long long t0 = 0; t0 * stride * PW_UNROLL < M; ++t0) {
+            f32x4 v[PW_UNROLL], r[PW_UNROLL];
+            long long mm[PW_UNROLL];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const long long m = ((t0 * gridDim.x + blockIdx.x) * UN + u) * rpb + rg;
+            for (int u = 0; u < PW_UNROLL; ++u) {
+                const long long m = ((t0 * gridDim.x + blockIdx.x) * PW_UNROLL + u) * rpb + rg;
                 mm[u] = m < M ? m : -1;
                 const long long ml = mm[u] < 0 ? 0 : mm[u];
                 v[u] = ld4y(y + ml * ldy, c0, ybf);
                 if (res) r[u] = ld4(res + ml * ldr + c0);
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
+            for (int u = 0; u < PW_UNROLL; ++u) {
                 if (mm[u] < 0) continue;
                 const long long m = mm[u];
                 f32x4 o;
@@ -470,7 +468,6 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
 }
 
 // backward pass 2: dy = gamma*invstd * (g - sum_g/M - xhat * sum_gx/M)
-template <int UN>
 __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
     const float* __restrict__ dz, long long lddz, const float* __restrict__ y, long long ldy,
     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -508,19 +505,19 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_apply_kernel(
             k2[e] = (float)(acc[C + c0 + e] * invM);
         }
         const long long stride = (long long)gridDim.x * rpb;
-        for (long long t0 = 0; t0 * stride * UN < M; ++t0) {
-            f32x4 v[UN], d[UN];
-            long long mm[UN];
+        for (long long t0 = 0; t0 * stride * PW_UNROLL < M; ++t0) {
+            f32x4 v[PW_UNROLL], d[PW_UNROLL];
+            long long mm[PW_UNROLL];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const long long m = ((t0 * gridDim.x + blockIdx.x) * UN + u) * rpb + rg;
+            for (int u = 0; u < PW_UNROLL; ++u) {
+                const long long m = ((t0 * gridDim.x + blockIdx.x) * PW_UNROLL + u) * rpb + rg;
                 mm[u] = m < M ? m : -1;
                 const long long ml = mm[u] < 0 ? 0 : mm[u];
                 v[u] = ld4y(y + ml * ldy, c0, ybf);
                 d[u] = ld4(dz + ml * lddz + c0);
             }
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
+            for (int u = 0; u < PW_UNROLL; ++u) {
                 if (mm[u] < 0) continue;
                 const long long m = mm[u];
                 f32x4 o;
@@ -923,14 +920,9 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (!vec_ok(y, ldy, C) || (z && !vec_ok(z, ldz, C)) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
         return Y4_ERR_SHAPE;
     const RowMap rm = row_map(C);
-    // a bf16 y is read with 8-B loads: twice the row groups in flight keep the bytes in flight (the sweeps are bound by
-    // memory-level parallelism: with four groups the halved bytes bought nothing, measured)
-    static const int un8 = getenv("Y4_BN_UN8") ? atoi(getenv("Y4_BN_UN8")) : 1;
-    const int UN = (ybf && un8) ? 8 : PW_UNROLL;
-    long long blocks = (M + rm.rpb * UN - 1) / (rm.rpb * UN);
+    long long blocks = (M + rm.rpb * PW_UNROLL - 1) / (rm.rpb * PW_UNROLL);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    auto kern = UN == 8 ? bn_act_fwd_kernel<8> : bn_act_fwd_kernel<PW_UNROLL>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
                        (long long)ldy, mean, invstd, gamma, beta, act, residual, (long long)ldr, z, (long long)ldz,
                        M, C, rm.tpr, rm.rpb, z_planes == 3 ? nullptr : out_amax, z_planes == 3 ? 2 : (z_planes ? 1 : 0), planes_twin, ybf);
     Y4_CHECK_LAUNCH();
@@ -968,12 +960,9 @@ static int bn_act_bwd_impl(const float* dz, int lddz, const float* y, int ldy,
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, bacc, nb, C, acc, dgamma, dbeta, gamma,
                        invstd, 1.0 / (double)M, f16_planes);
     Y4_CHECK_LAUNCH();
-    static const int un8 = getenv("Y4_BN_UN8") ? atoi(getenv("Y4_BN_UN8")) : 1;
-    const int UN = (ybf && un8) ? 8 : PW_UNROLL;           // (as in y4_bn_act_fwd_f32)
-    long long blocks = (M + rm.rpb * UN - 1) / (rm.rpb * UN);
+    long long blocks = (M + rm.rpb * PW_UNROLL - 1) / (rm.rpb * PW_UNROLL);
     if (blocks > 256 * 16) blocks = 256 * 16;
-    auto akern = UN == 8 ? bn_act_bwd_apply_kernel<8> : bn_act_bwd_apply_kernel<PW_UNROLL>;
-    hipLaunchKernelGGL(akern, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, st, dz, (long long)lddz, y,
                        (long long)ldy, mean, invstd, gamma, beta, act, acc, dy, (long long)lddy, M, C, rm.tpr, rm.rpb,
                        out_amax, f16_planes, frozen ? 1 : 0, bf, planes_twin, ybf);
     Y4_CHECK_LAUNCH();

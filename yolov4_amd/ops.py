@@ -239,7 +239,11 @@ def planes_stride2_ok(k, s, H, W):
 
 
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
-_BF16_Y = os.environ.get('Y4_BF16_Y', '1') != '0'            # (A/B switch: bf16 conv results on the plane layers of conv mode 'bf16')
+# bf16 conv RESULTS on the plane layers of conv mode 'bf16' (y4_conv2d_fwd_planes_f32 y_bf16): built, bit-exact against its
+# definition (tests/test_gpu_planes.py), and OFF by default -- the three BatchNorm sweeps that read y are bound by the bytes they
+# keep in flight, not by the bytes they move: with 8-B instead of 16-B loads per lane the step time did not change (599.0 vs
+# 600.5 img/s at bs = 128, A/B on one box), and twice the row groups in flight cost the sweeps their occupancy (550 img/s)
+_BF16_Y = os.environ.get('Y4_BF16_Y', '0') == '1'
 
 
 def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
