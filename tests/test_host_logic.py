@@ -30,7 +30,7 @@ def test_convbnact_ctx_does_not_hold_its_output(monkeypatch):
         y = torch.nn.functional.conv2d(x, w, None, s, (k - 1) // 2)
         return y, y.mean((0, 2, 3)), (y.var((0, 2, 3), unbiased=False) + eps).rsqrt()
 
-    def fake_bn_act(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None):
+    def fake_bn_act(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None, **kw):
         z = (y - mean.view(1, -1, 1, 1)) * (invstd * gamma).view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
         if out is not None:
             out.copy_(z)
@@ -39,6 +39,7 @@ def test_convbnact_ctx_does_not_hold_its_output(monkeypatch):
 
     monkeypatch.setattr(ops, '_require_gpu', lambda t, what: None)
     monkeypatch.setattr(ops, 'f16x2_mode', lambda: False)      # no operand maxima (device kernels) in this host-logic test
+    monkeypatch.setattr(ops, 'planes_mode', lambda: None)
     monkeypatch.setattr(ops, 'conv_fwd_bnstats_raw', fake_bnstats)
     monkeypatch.setattr(ops, 'bn_act_fwd_raw', fake_bn_act)
     m = ConvBNAct(8, 8, 1, 1).train()
