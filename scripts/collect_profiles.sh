@@ -41,7 +41,12 @@ for what in "$@"; do
     stats)     run_pass stats 400 rocprofv3 --kernel-trace --stats -d . -o train --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-infer-leg --conv-table conv_table.txt || exit 1 ;;
     fetch)     run_pass fetch 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d . -o f --output-format csv -- python3 $R/bench.py $STEPS || exit 1 ;;
     write)     run_pass write 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d . -o w --output-format csv -- python3 $R/bench.py $STEPS || exit 1 ;;
-    mfma)      run_pass mfma 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d . -o m --output-format csv -- python3 $R/bench.py $STEPS || exit 1 ;;
+    # The SQ-counter pass: counters only for the kernels that have MFMAs to count, and 3 steps instead of 7.  In rounds 3 and 4 the
+    # UNRESTRICTED pass (7 steps, ~11 600 serialized dispatches) hung in 4 of 11 attempts -- in round 4, with this script's
+    # per-pass records, at dispatch 11 376 of 11 625 (counter file complete up to there), in the middle of the seventh identical
+    # backward pass: inside the profiler's per-dispatch counter start / stop, not at a particular kernel of the library
+    # (profiles/r04_profiler_passes/mfma_20261005T071003Z/).  ~1 000 serialized dispatches instead.
+    mfma)      run_pass mfma 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "conv|wgrad" -d . -o m --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-infer-leg || exit 1 ;;
     infer)     run_pass infer 400 rocprofv3 --kernel-trace --stats -d . -o infer --output-format csv -- python3 $R/bench.py --infer --steps 10 --warmup 2 || exit 1 ;;
     ifetch)    run_pass ifetch 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d . -o f --output-format csv -- python3 $R/bench.py --infer --steps 3 --warmup 1 || exit 1 ;;
     iwrite)    run_pass iwrite 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d . -o w --output-format csv -- python3 $R/bench.py --infer --steps 3 --warmup 1 || exit 1 ;;
@@ -50,7 +55,7 @@ for what in "$@"; do
                unset Y4_FORCE_DIST ;;
     bf16)      run_pass bf16 400 python3 $R/bench.py $BF --steps 6 --warmup 2 --no-cpu-baseline --no-infer-leg || exit 1 ;;
     bf16stats) run_pass bf16stats 400 rocprofv3 --kernel-trace --stats -d . -o train --output-format csv -- python3 $R/bench.py $BF --steps 6 --warmup 2 --no-cpu-baseline --no-infer-leg --conv-table conv_table.txt || exit 1 ;;
-    bf16mfma)  run_pass bf16mfma 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d . -o m --output-format csv -- python3 $R/bench.py $BF --steps 3 --warmup 2 --no-cpu-baseline --no-infer-leg || exit 1 ;;
+    bf16mfma)  run_pass bf16mfma 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-include-regex "conv|wgrad" -d . -o m --output-format csv -- python3 $R/bench.py $BF --steps 2 --warmup 1 --no-cpu-baseline --no-infer-leg || exit 1 ;;
     *) echo "unknown step $what"; exit 2 ;;
   esac
   sleep 3
