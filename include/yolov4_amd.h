@@ -158,7 +158,7 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
                                 with y4_bn_act_fwd_f32 z_planes + 16 / y4_bn_act_bwd_f32 frozen_stats bit 2 */,
                              void* stream);
 
-/* dgrad (stride 1) / wgrad (stride 1, and the 3x3 stride-2 layers on even maps) of a conv over planes (dy, and for wgrad also
+/* dgrad / wgrad (stride 1, and the 3x3 stride-2 layers on even maps) of a conv over planes (dy, and for wgrad also
  * x, pre-split as above; Cin % 32 == 0, Cout % 32 == 0): the same arithmetic as y4_conv2d_dgrad_f32 / y4_conv2d_wgrad_f32 in
  * conv mode 3 (conv mode 2: plain bf16 operands, 64-channel multiples, stride 1).  dgrad runs the forward DMA kernel on the
  * mirrored transposed filter (workspace: y4_conv2d_dgrad_workspace()); wgrad stages both operands pixel-major and takes its
@@ -166,6 +166,9 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
  * reduce: deterministic); H, W are the INPUT dims.  Autograd of the same nn.Conv2d, darknet/darknet.py:31-36. */
 int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w /* NULL: workspace prepared by the forward call */, float* dx, int lddx,
                                int B, int H, int W, int Cin, int Cout, int k,
+                               int stride /* 1; or 2 (3x3, H and W even, conv mode 3 operands, no residual): four launches, one per
+                                  parity class of dx over its 1 / 2 / 2 / 4 taps; the workspace then holds the UN-mirrored
+                                  transposed planes (what the forward call prepares for a stride-2 layer) */,
                                void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                                const float* residual, int ldr, void* stream);
 size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, int k, int stride);

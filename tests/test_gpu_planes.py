@@ -377,6 +377,17 @@ def test_planes_stride2_wgrad_and_forward_match_torch(dev, case):
     assert err < 3e-6, err
     dw0 = ops.conv_wgrad_raw(xd, dyd, (co, ci, k, k), k, s)
     assert float((dw - dw0).abs().max()) <= 3e-6 * float(dw_ref.abs().max())
+    # dgrad: four launches of the forward kernel, one per parity class of dx (1 / 2 / 2 / 4 taps each)
+    dx = ops.conv_dgrad_planes_raw(dyp, wd, (B, ci, H, W), k, s=2)
+    torch.cuda.synchronize()
+    assert ops.last_conv_kernel().endswith('false, false, true>'), ops.last_conv_kernel()
+    dx_ref = torch.nn.grad.conv2d_input((B, ci, H, W), w.double(), dy.double(), s, 1)
+    assert float((dx.double().cpu() - dx_ref).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+    dx0 = ops.conv_dgrad_raw(dyd, wd, (B, ci, H, W), k, s)
+    assert float((dx - dx0).abs().max()) <= 2e-6 * float(dx_ref.abs().max())
+    buf = ops.dgrad_filter_buffer(ci, co, k, dev)      # ... and on the planes the forward call prepares for a stride-2 layer
+    ops.conv_fwd_planes_raw(xp, wd, k, s, dgrad_filter=buf)
+    assert torch.equal(dx, ops.conv_dgrad_planes_raw(dyp, wd, (B, ci, H, W), k, s=2, prepared=buf))
 
 
 def test_stride2_module_through_planes_matches_the_fp32_tensor_path(dev):

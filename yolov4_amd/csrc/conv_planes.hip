@@ -45,6 +45,11 @@ struct PlaneConvGeom {
     const float* res; long long ldr;   // optional: added in the epilogue (dgrad: gradient arriving over a skip connection)
     float* stats;                      // optional: per-M-tile column sums [mtiles][2][N] of the result
     int dst_bf16;                      // the result leaves as bf16 (RN) in the first half of each fp32-sized row (pitch 4 ldd bytes)
+    // DG2 (dgrad of a 3x3 stride-2 conv, one launch per parity class (ph, pw) of the dx grid): the rows are the class's pixels
+    // (hc, wc) <-> dx pixel (2 hc + ph, 2 wc + pw) of an Hfull x Wfull map (Hd, Wd = Hfull / 2, Wfull / 2); the class's 1 / 2 /
+    // 2 / 4 taps read dy pixel (hc + dh, wc + dw), dh, dw in {0, 1}, and filter K-tile group `slot` (= tap r * 3 + q)
+    int cls_ntaps, cls_ph, cls_pw, Hfull, Wfull;
+    int cls_dh[4], cls_dw[4], cls_slot[4];
     int B, Hs, Ws, Cs, Hd, Wd, N, k, stride, pad, M, K;
     int mtiles, ntiles;
     unsigned long long src_total_bytes;
@@ -75,7 +80,9 @@ __device__ __forceinline__ f32x4v pl_mma(const f16x8 a, const f16x8 b, const f32
 
 // YB (with BF): the result leaves as bf16 (PlaneConvGeom::dst_bf16) -- a variant of its own, so that the three store forms of
 // the epilogue do not share one register allocation (as run-time branches they cost the 128 x 64 wave tile 14 spills)
-template <int BM, int BN, int WM, int WN, bool BF, bool YB = false>
+// DG2: the parity-class dgrad of the 3x3 stride-2 layers (PlaneConvGeom::cls_*): a tap list instead of the k x k raster, and a
+// scattered destination (every second pixel of every second row).
+template <int BM, int BN, int WM, int WN, bool BF, bool YB = false, bool DG2 = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_planes_mfma(const PlaneConvGeom g) {
     constexpr int NWAVE = WM * WN, NTHR = NWAVE * 64;
     static_assert(NWAVE == 8 || NWAVE == 4, "8 or 4 waves");
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
     const int mt = lt / g.ntiles, nt = lt - mt * g.ntiles;
     const int n0 = nt * BN;
     const int CC = g.Cs >> KSH;
-    const int KT = g.k * g.k * CC;
+    const int KT = (DG2 ? g.cls_ntaps : g.k * g.k) * CC;
 
     // ---- 32-bit window of the source tensor, re-based at the first image this tile touches
     const int pix_per_img = g.Hd * g.Wd;
@@ -122,13 +129,18 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
         const int b = mm / pix_per_img;
         const int rem = mm - b * pix_per_img;
         const int hd = rem / g.Wd, wd = rem - hd * g.Wd;
-        const int hc = hd * g.stride - g.pad, wc = wd * g.stride - g.pad;
+        const int hc = DG2 ? hd : hd * g.stride - g.pad, wc = DG2 ? wd : wd * g.stride - g.pad;
         const int chunk = pos ^ ((row >> 1) & 7);
         a_base[i] = (unsigned)(((b - b_first) * g.Hs + hc) * g.Ws + wc) * pitch + (unsigned)chunk * 16u;   // mod 2^32
         unsigned v = 0u;
-        for (int r = 0; r < g.k; ++r)
-            for (int q = 0; q < g.k; ++q)
-                if (ok && (unsigned)(hc + r) < (unsigned)g.Hs && (unsigned)(wc + q) < (unsigned)g.Ws) v |= 1u << (r * g.k + q);
+        if constexpr (DG2) {
+            for (int t = 0; t < g.cls_ntaps; ++t)
+                if (ok && hc + g.cls_dh[t] < g.Hs && wc + g.cls_dw[t] < g.Ws) v |= 1u << t;
+        } else {
+            for (int r = 0; r < g.k; ++r)
+                for (int q = 0; q < g.k; ++q)
+                    if (ok && (unsigned)(hc + r) < (unsigned)g.Hs && (unsigned)(wc + q) < (unsigned)g.Ws) v |= 1u << (r * g.k + q);
+        }
         a_valid[i] = v;
     }
     unsigned b_off[PB];
@@ -140,8 +152,17 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
     }
     // ---- DMA issue state: the K-tile (ld_tap, ld_cc) whose pieces are going out next; taps outer, channel chunks inner
     int ld_tap = 0, ld_r = 0, ld_q = 0, ld_cc = 0;
+    int ld_slot = DG2 ? g.cls_slot[0] : 0;                 // filter K-tile group of the tap under way (DG2: from the class's list)
     auto tap_setup = [&]() {
-        const unsigned toff = (unsigned)(ld_r * g.Ws + ld_q) * pitch;
+        unsigned toff;
+        if constexpr (DG2) {
+            const int t = ld_tap < g.cls_ntaps ? ld_tap : 0;
+            toff = (unsigned)(g.cls_dh[t] * g.Ws + g.cls_dw[t]) * pitch;
+            ld_slot = g.cls_slot[t];
+        } else {
+            toff = (unsigned)(ld_r * g.Ws + ld_q) * pitch;
+            ld_slot = ld_tap;
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) a_voff[i] = ((a_valid[i] >> ld_tap) & 1u) ? a_base[i] + toff : OOB;
     };
@@ -152,7 +173,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
         constexpr int p0 = decltype(P0)::value, p1 = decltype(P1)::value;
         unsigned char* st = smem + stage * STAGE;
         const unsigned soff_a = (unsigned)ld_cc * 128u;
-        const unsigned soff_b = (unsigned)(ld_tap * CC + ld_cc) * 128u;
+        const unsigned soff_b = (unsigned)(ld_slot * CC + ld_cc) * 128u;
 #pragma unroll
         for (int p = p0; p < p1; ++p) {
             if (p < PA)
@@ -313,7 +334,30 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
         const int fr = lane_e & 15, kq = lane_e >> 4;
         const int colb = n0 + wn * WTN + fr;
         const bool allc = n0 + BN <= g.N;
-        if constexpr (!YB) {
+        if constexpr (DG2) {
+            // scattered destination: row m of the class grid -> dx pixel (b, 2 hc + ph, 2 wc + pw); one division pair per 4-row
+            // group of a lane, the other three rows by stepping (wc, hc, b).  Window: the whole dx tensor (< 4 GiB, host-checked)
+            const __amdgpu_buffer_rsrc_t xrs = y4_make_rsrc(g.dst, (unsigned)((unsigned long long)g.B * g.Hfull * g.Wfull * drow));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m0 = mt * BM + wm * WTM + 16 * i + 4 * kq;
+                int b = m0 / pix_per_img;
+                const int rem = m0 - b * pix_per_img;
+                int hc = rem / g.Wd, wc = rem - hc * g.Wd;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool rok = m0 + e < g.M;
+                    const unsigned po = (unsigned)((b * g.Hfull + 2 * hc + g.cls_ph) * g.Wfull + 2 * wc + g.cls_pw) * drow + (unsigned)colb * 4u;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float v = result(i, j, e);
+                        const bool cok = rok && (allc || colb + 16 * j < g.N);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), xrs, (int)(cok ? po + 64u * j : 0xffffffffu), 0, 0);
+                    }
+                    if (++wc == g.Wd) { wc = 0; if (++hc == g.Hd) { hc = 0; ++b; } }
+                }
+            }
+        } else if constexpr (!YB) {
         if (g.res) {
             // skip operand (dgrad: the gradient arriving over a ResBlock skip connection): the 4 x TN loads of a row tile all go
             // out before the first of them is needed -- issued one by one in front of their stores, each store waited for
@@ -804,7 +848,7 @@ int bf16_filter(const float* w, unsigned short* fwd, unsigned short* tr, int Cou
     return Y4_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool BF, bool YB = false>
+template <int BM, int BN, int WM, int WN, bool BF, bool YB = false, bool DG2 = false>
 int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     PlaneConvGeom g = g0;
     g.mtiles = (g.M + BM - 1) / BM;
@@ -814,10 +858,11 @@ int launch_conv_planes(const PlaneConvGeom& g0, hipStream_t st) {
     constexpr size_t smem = ((NW == 8 && 3 * stage <= 160 * 1024) ? 3ull : 2ull) * stage;   // the stages; the epilogue needs WM * BN * 8 B of them
     static_assert(NW == 8 || 2 * smem <= 160 * 1024, "two blocks per CU");
     static_assert(smem <= 160 * 1024, "LDS");
-    auto kern = conv_planes_mfma<BM, BN, WM, WN, BF, YB>;
+    auto kern = conv_planes_mfma<BM, BN, WM, WN, BF, YB, DG2>;
     static Y4DynLds lds_attr;                              // per device, see common.h
     if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
-    y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d, %s, %s>", BM, BN, WM, WN, BF ? "true" : "false", YB ? "true" : "false");
+    y4::note_kernel("conv_planes_mfma<%d, %d, %d, %d, %s, %s, %s>", BM, BN, WM, WN, BF ? "true" : "false", YB ? "true" : "false",
+                    DG2 ? "true" : "false");
     hipLaunchKernelGGL(kern, dim3(g.mtiles * g.ntiles), dim3(NW * 64), smem, st, g);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
@@ -891,6 +936,44 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
     if (dst_bf16) return Y4_ERR_SHAPE;                     // (bf16 results: the bf16 operand kernels only)
     if (nparts) *nparts = small ? (g.M + 127) / 128 : (g.M + 255) / 256;
     return small ? launch_conv_planes<128, 128, 2, 2, false>(g, st) : launch_conv_planes<256, 128, 4, 2, false>(g, st);
+}
+
+// dgrad of a 3x3 stride-2 conv over dy planes [B][Ho][Wo][Cout] (H = 2 Ho, W = 2 Wo): four forward-form launches, one per parity
+// class of the dx grid, each over its own 1 / 2 / 2 / 4 taps of the TRANSPOSED (un-mirrored) filter planes [Cin][9][Cout]
+int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_planes, const unsigned* wt_amax, float* dx, long long lddx,
+                    int B, int H, int W, int Cin, int Cout, hipStream_t st) {
+    if ((H & 1) || (W & 1) || (Cout & 31) || (Cin & 3)) return Y4_ERR_SHAPE;
+    const int Ho = H / 2, Wo = W / 2;
+    PlaneConvGeom g{};
+    g.src = static_cast<const unsigned char*>(dy); g.wt = static_cast<const unsigned char*>(wt_planes);
+    g.dst = dx; g.ldd = lddx;
+    g.B = B; g.Hs = Ho; g.Ws = Wo; g.Cs = Cout; g.N = Cin; g.k = 3; g.stride = 1; g.pad = 0;
+    g.Hd = Ho; g.Wd = Wo; g.Hfull = H; g.Wfull = W;
+    const long long M = (long long)B * Ho * Wo;
+    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
+    g.M = (int)M; g.K = 9 * Cout;
+    const unsigned long long img = (unsigned long long)Ho * Wo * (unsigned long long)Cout * 4ull;
+    const unsigned long long wb = (unsigned long long)Cin * g.K * 4ull;
+    const unsigned long long imgs_per_tile = 256ull / (unsigned long long)(Ho * Wo > 0 ? Ho * Wo : 1) + 2;
+    if (img * imgs_per_tile >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+    if ((unsigned long long)B * H * W * (unsigned long long)lddx * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
+    g.src_total_bytes = (unsigned long long)B * img;
+    g.wt_bytes = (unsigned)wb;
+    g.src_amax = dy_amax; g.wt_amax = wt_amax;
+    // heaviest class first (4 taps), so that the launch that ends the sequence is the short one
+    for (int c = 3; c >= 0; --c) {
+        const int ph = c >> 1, pw = c & 1;
+        g.cls_ph = ph; g.cls_pw = pw; g.cls_ntaps = 0;
+        for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) {
+                if (((ph + 1 - r) & 1) || ((pw + 1 - q) & 1)) continue;
+                const int t = g.cls_ntaps++;
+                g.cls_dh[t] = (ph + 1 - r) / 2; g.cls_dw[t] = (pw + 1 - q) / 2; g.cls_slot[t] = r * 3 + q;
+            }
+        const int rc = launch_conv_planes<256, 128, 4, 2, false, false, true>(g, st);
+        if (rc != Y4_OK) return rc;
+    }
+    return Y4_OK;
 }
 
 // split-K plan of the plane wgrad: tiles x splits blocks on 256 CUs (one block per CU), minimising rounds x K-steps per block
@@ -1062,13 +1145,29 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
 
 // dgrad of a stride-1 conv over dy planes: the forward kernel on the mirrored, transposed filter (N = Cin, K = k*k*Cout)
 int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx, int lddx,
-                               int B, int H, int W, int Cin, int Cout, int k,
+                               int B, int H, int W, int Cin, int Cout, int k, int stride,
                                void* workspace, size_t workspace_bytes, const unsigned* dy_amax,
                                const float* residual, int ldr, void* stream) {
     if (!dy_planes || !dx || !workspace) return Y4_ERR_NULL;     // w == NULL: workspace filled by the forward call
     if (!pl_mode_ok()) return Y4_ERR_SHAPE;
     const bool bf = pl_bf();
     if (!bf && !dy_amax) return Y4_ERR_NULL;
+    if (stride == 2) {
+        // 3x3 stride 2 on an even map (f16x2 operands): one launch per parity class on the un-mirrored transposed planes
+        if (bf || k != 3 || residual || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || !y4::planes_conv_ok(Cout, Cin, k, 1) ||
+            lddx < Cin || (lddx & 3)) return Y4_ERR_SHAPE;
+        if (workspace_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
+        if ((reinterpret_cast<uintptr_t>(dy_planes) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
+            (reinterpret_cast<uintptr_t>(workspace) & 15) || (reinterpret_cast<uintptr_t>(dx) & 15)) return Y4_ERR_SHAPE;
+        hipStream_t st2 = y4_stream(stream);
+        unsigned* hdr2 = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)Cin * 9 * Cout * 6);
+        if (w) {
+            const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, 9, Cout, hdr2, hdr2 + 16, st2, false);
+            if (rc != Y4_OK) return rc;
+        }
+        return y4::planes_dgrad_s2(dy_planes, dy_amax, workspace, hdr2, dx, lddx, B, H, W, Cin, Cout, st2);
+    }
+    if (stride != 1) return Y4_ERR_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cout, Cin, k, 1) || lddx < Cin || (lddx & 3)) return Y4_ERR_SHAPE;
     if (bf && (Cout & 63)) return Y4_ERR_SHAPE;
     if (residual && (ldr < Cin || (ldr & 3) || (reinterpret_cast<uintptr_t>(residual) & 15))) return Y4_ERR_SHAPE;

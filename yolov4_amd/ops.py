@@ -239,6 +239,7 @@ def planes_stride2_ok(k, s, H, W):
 
 
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
+_S2_DGRAD_PLANES = os.environ.get('Y4_PLANES_S2_DGRAD', '1') != '0'      # (A/B switch: 0 = register-staged stride-2 dgrad over an fp32 twin of dy)
 # bf16 conv RESULTS on the plane layers of conv mode 'bf16' (y4_conv2d_fwd_planes_f32 y_bf16): built, bit-exact against its
 # definition (tests/test_gpu_planes.py), and OFF by default -- the three BatchNorm sweeps that read y are bound by the bytes they
 # keep in flight, not by the bytes they move: with 8-B instead of 16-B loads per lane the step time did not change (599.0 vs
@@ -457,8 +458,9 @@ def planes_of(t):
     return Planes(t, t.shape, getattr(t, 'y4_amax', None))
 
 
-def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None, prepared=None):
-    """dx of a stride-1 conv from a Planes dy (the DMA forward kernel on the mirrored transposed filter)."""
+def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None, prepared=None, s=1):
+    """dx of a conv from a Planes dy: stride 1 (the DMA forward kernel on the mirrored transposed filter), or 3x3 stride 2 on an
+    even map (one launch per parity class of dx)."""
     L = lib()
     B, Cin, H, W = x_shape
     Cout = w.shape[0]
@@ -469,7 +471,7 @@ def conv_dgrad_planes_raw(dyp, w, x_shape, k, residual=None, prepared=None):
     if residual is not None:
         residual, ldr = as_nhwc(residual)
     check(L.y4_conv2d_dgrad_planes_f32(_ptr(dyp.buf), None if prepared is not None else _ptr(krsc(w)), _ptr(dx), nhwc_pitch(dx), B, H, W, Cin, Cout, k,
-                                       _ptr(ws), nbytes, _ptr(dyp.amax), _ptr(residual), ldr, _stream()), 'conv2d_dgrad_planes')
+                                       s, _ptr(ws), nbytes, _ptr(dyp.amax), _ptr(residual), ldr, _stream()), 'conv2d_dgrad_planes')
     return dx
 
 
@@ -923,7 +925,8 @@ class ConvBNActFn(torch.autograd.Function):
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
             # stride 2 over planes: wgrad runs on the plane kernel, dgrad on the register-staged parity-class kernel, which
             # wants fp32 -- dy leaves the sweep both ways (the bound in word [5] dominates max|dy|: it serves both as scale)
-            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0]
+            # (f16x2 operands: the plane kernel runs the stride-2 dgrad too, class by class -- no fp32 copy)
+            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and (bfp or not _S2_DGRAD_PLANES)
             res = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                  gp.grad if sink else None, bp.grad if sink else None,
                                  out_amax=None if planes is not None else dy_amax, planes=planes,
@@ -954,9 +957,9 @@ class ConvBNActFn(torch.autograd.Function):
                 dx = conv_stem_dgrad_raw(dy, weight, x)       # gradient wrt the network input (never needed in training)
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
-            elif x_planes and s == 1:
+            elif x_planes and (s == 1 or not twin_dy):
                 dx = conv_dgrad_planes_raw(Planes(dy, dy.shape, dy_amax), weight, ctx.x_shape, k, residual=skip_grad,
-                                           prepared=getattr(ctx, 'dgrad_filter', None))
+                                           prepared=getattr(ctx, 'dgrad_filter', None), s=s)
             else:
                 dx = conv_dgrad_raw(dy, weight, ctx.x_shape, k, s, dy_amax=dy_amax, residual=skip_grad,
                                     prepared=getattr(ctx, 'dgrad_filter', None) if f16x2_mode() else None)
