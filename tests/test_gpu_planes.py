@@ -504,7 +504,7 @@ def test_bf16_conv_result_and_batchnorm_sweeps_over_it(dev, bf16_mode, case):
     y32 = ops.conv_fwd_planes_raw(xp, wd, k, s, stats=False)
     yb, part, n = ops.conv_fwd_planes_raw(xp, wd, k, s, y_bf16=True)
     torch.cuda.synchronize()
-    assert 'true, true>' in ops.last_conv_kernel(), ops.last_conv_kernel()
+    assert 'true, true, false>' in ops.last_conv_kernel(), ops.last_conv_kernel()
     got = _bf16_payload(yb)
     assert torch.equal(got, y32.bfloat16().float())                         # RN-even of the very same accumulators
     st = part.view(torch.float32)[:n * 2 * co].view(n, 2, co).double().sum(0).cpu()
