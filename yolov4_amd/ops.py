@@ -926,7 +926,8 @@ class ConvBNActFn(torch.autograd.Function):
             # stride 2 over planes: wgrad runs on the plane kernel, dgrad on the register-staged parity-class kernel, which
             # wants fp32 -- dy leaves the sweep both ways (the bound in word [5] dominates max|dy|: it serves both as scale)
             # (f16x2 operands: the plane kernel runs the stride-2 dgrad too, class by class -- no fp32 copy)
-            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and (bfp or not _S2_DGRAD_PLANES)
+            # and not with fewer than 128 input channels (half-empty column tiles: 64->128 @304 took 1.81 ms there, 1.24 + 0.14 this way)
+            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and (bfp or not _S2_DGRAD_PLANES or ctx.x_shape[1] < 128)
             res = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                  gp.grad if sink else None, bp.grad if sink else None,
                                  out_amax=None if planes is not None else dy_amax, planes=planes,
