@@ -348,6 +348,70 @@ __global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_kernel(
     if (out_amax && !planes) amax_commit(amax, out_amax);
 }
 
+// The same sweep for a bf16 y WITHOUT a skip operand (conv mode 'bf16', y4_conv2d_fwd_planes_f32 y_bf16): the sweeps are bound by
+// the bytes they keep IN FLIGHT, so a y of half the width wants twice the row groups per trip -- the loaded values stay packed
+// (two registers per four channels) until they are used, which keeps the register count, hence the occupancy, of the fp32 form.
+__global__ __launch_bounds__(PW_THREADS) void bn_act_fwd_bf16y_kernel(
+    const float* __restrict__ y, long long ldy, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* __restrict__ z, long long ldz,
+    long long M, int C, int tpr, int rpb, unsigned* __restrict__ out_amax, int planes, float* __restrict__ twin) {
+    constexpr int UN = 2 * PW_UNROLL;
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x;
+    const int cv = tid % tpr, rg = tid / tpr;
+    unsigned amax = 0u;
+    float ps = 1.f;
+    const bool paired = (C & 7) == 0 && tpr >= 2;
+    if (planes == 1) {
+        const unsigned e8 = (*out_amax >> 23) & 0xffu;
+        int se = 268 - (int)e8;
+        if (e8 == 0u || e8 == 255u) se = 127;
+        se = se < 2 ? 2 : (se > 252 ? 252 : se);
+        ps = __uint_as_float((unsigned)se << 23);
+    }
+    for (int c0 = cv * 4; c0 < C; c0 += tpr * 4) {
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = invstd[c0 + e] * gamma[c0 + e];
+            b[e] = beta[c0 + e] - mean[c0 + e] * a[e];
+        }
+        const long long stride = (long long)gridDim.x * rpb;
+        for (long long t0 = 0; t0 * stride * UN < M; ++t0) {
+            u2v v[UN];
+            int mm[UN];                                    // row relative to the trip's first row (M < 2^31 rows per trip span)
+            const long long mbase = (t0 * gridDim.x + blockIdx.x) * UN * rpb + rg;
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long long m = mbase + (long long)u * rpb;
+                mm[u] = m < M ? u : -1;
+                const long long ml = m < M ? m : 0;
+                v[u] = *reinterpret_cast<const u2v*>(reinterpret_cast<const unsigned char*>(y + ml * ldy) + c0 * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                if (mm[u] < 0) continue;
+                const long long m = mbase + (long long)u * rpb;
+                f32x4 vv, o;
+                vv[0] = __uint_as_float(v[u][0] << 16); vv[1] = __uint_as_float(v[u][0] & 0xffff0000u);
+                vv[2] = __uint_as_float(v[u][1] << 16); vv[3] = __uint_as_float(v[u][1] & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = y4_act(vv[e] * a[e] + b[e], act);
+                if (planes) {
+                    unsigned char* row = reinterpret_cast<unsigned char*>(twin ? twin + m * (long long)C : z + m * ldz);
+                    if (planes == 2) store_bf16x4(row, c0, o);
+                    else store_planes4(row, c0, o, ps, paired);
+                    if (twin) st4(z + m * ldz + c0, o);
+                } else {
+                    if (z) st4(z + m * ldz + c0, o);
+                    amax_track(amax, o);
+                }
+            }
+        }
+    }
+    if (out_amax && !planes) amax_commit(amax, out_amax);
+}
+
 // backward pass 1: sum_g[c] = sum_m g, sum_gx[c] = sum_m g * xhat,  g = dz * act'(u)
 __global__ __launch_bounds__(PW_THREADS) void bn_act_bwd_reduce_kernel(
     const float* __restrict__ dz, long long lddz, const float* __restrict__ y, long long ldy,
@@ -920,6 +984,15 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (!vec_ok(y, ldy, C) || (z && !vec_ok(z, ldz, C)) || (residual && !vec_ok(residual, ldr, C)) || M <= 0)
         return Y4_ERR_SHAPE;
     const RowMap rm = row_map(C);
+    if (ybf && !residual) {                                // bf16 y, no skip operand: twice the row groups in flight, packed
+        long long blocks2 = (M + rm.rpb * 2 * PW_UNROLL - 1) / (rm.rpb * 2 * PW_UNROLL);
+        if (blocks2 > 256 * 16) blocks2 = 256 * 16;
+        hipLaunchKernelGGL(bn_act_fwd_bf16y_kernel, dim3((unsigned)blocks2), dim3(PW_THREADS), 0, y4_stream(stream), y,
+                           (long long)ldy, mean, invstd, gamma, beta, act, z, (long long)ldz, M, C, rm.tpr, rm.rpb,
+                           z_planes == 3 ? nullptr : out_amax, z_planes == 3 ? 2 : (z_planes ? 1 : 0), planes_twin);
+        Y4_CHECK_LAUNCH();
+        return Y4_OK;
+    }
     long long blocks = (M + rm.rpb * PW_UNROLL - 1) / (rm.rpb * PW_UNROLL);
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(bn_act_fwd_kernel, dim3((unsigned)blocks), dim3(PW_THREADS), 0, y4_stream(stream), y,
