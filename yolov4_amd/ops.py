@@ -243,7 +243,10 @@ _S2_DGRAD_PLANES = os.environ.get('Y4_PLANES_S2_DGRAD', '1') != '0'      # (A/B 
 # bf16 conv RESULTS on the plane layers of conv mode 'bf16' (y4_conv2d_fwd_planes_f32 y_bf16): built, bit-exact against its
 # definition (tests/test_gpu_planes.py), and OFF by default -- the three BatchNorm sweeps that read y are bound by the bytes they
 # keep in flight, not by the bytes they move: with 8-B instead of 16-B loads per lane the step time did not change (599.0 vs
-# 600.5 img/s at bs = 128, A/B on one box), and twice the row groups in flight cost the sweeps their occupancy (550 img/s)
+# 600.5 img/s at bs = 128, A/B on one box), and twice the row groups in flight cost the sweeps their occupancy (550 img/s);
+# with a forward sweep of its own that keeps the loaded bf16 values packed (bn_act_fwd_bf16y_kernel: 8 row groups at the
+# register count of 4) it is worth 0.8 % (605.4 vs 600.6 img/s) -- most BatchNorm bytes of the step belong to the stage-1 / 2
+# maps, which are not plane layers.  Not worth a second rounding of every conv result by default.
 _BF16_Y = os.environ.get('Y4_BF16_Y', '0') == '1'
 
 
