@@ -51,7 +51,7 @@ class ConvBNAct(nn.Module):
         self.stride = stride
         self.has_bn = bool(bn)
 
-    def forward(self, x, residual=None, out=None, dres_put=None, dres_take=None, out_planes=False):
+    def forward(self, x, residual=None, out=None, dres_put=None, dres_take=None, out_planes=False, dx_put=None):
         """out: optional destination (a CatBuffer slot) for the activation; dres_put / dres_take: the shared box through
         which a ResBlock unit's 3x3 conv hands the skip gradient to its 1x1 conv (see ResBlock); out_planes: the caller
         guarantees that the SOLE consumer of the result is a ConvBNAct for which `takes_planes()` holds, so the
@@ -63,7 +63,7 @@ class ConvBNAct(nn.Module):
         out_planes = soft(out_planes, self)
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
-               'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes,
+               'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes, 'dx_put': dx_put,
                'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self, x.shape[2:]) else None,
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:
@@ -173,6 +173,18 @@ def res_unit(pair, x, out_planes=False):
 # A residual unit's result feeds the next unit's 1x1 conv AND its skip: fp32 for the skip plus a pre-split twin for the conv
 # ('both') puts those 1x1 convs on the plane kernels at the price of one more 4-B/element write per unit (Y4_TWIN_RES=0: off)
 _TWIN_RES = os.environ.get('Y4_TWIN_RES', '1') != '0'
+# The gradient fan-in of a CSP fork (the stride-2 conv's result feeds the two 1x1 split convs): the split conv whose backward
+# runs first parks its dx, the other adds it in its dgrad epilogue instead of a separate add pass (Y4_FORK_FOLD=0: off)
+_FORK_FOLD = os.environ.get('Y4_FORK_FOLD', '1') != '0'
+
+
+def fork_box(x, *convs):
+    """Shared box for two ConvBNAct readers of x (see _FORK_FOLD), or None when the fold does not apply."""
+    if not (_FORK_FOLD and torch.is_grad_enabled() and x.requires_grad and not observed(*convs)):
+        return None
+    if not all(isinstance(m, ConvBNAct) and m.training and m.has_bn and m.kernel_size == 1 and m.stride == 1 for m in convs):
+        return None
+    return {}
 
 
 class ResBlock(nn.Module):
@@ -219,8 +231,9 @@ class CSPDownSample0(nn.Module):
         take pre-split inputs the transition conv writes its result that way."""
         xa, xb = ops.fork(self.base(x))
         cb = ops.cat_buffer(xa, [self.part2_2.conv.out_channels, self.part1.conv.out_channels])
-        x1 = self.part1(xa, out=cb.slot(1))
-        x2 = res_unit(self.part2_1_2, self.part2_1_1(xb))
+        fb = fork_box(xa, self.part1, self.part2_1_1)
+        x1 = self.part1(xa, out=cb.slot(1), dres_take=fb)
+        x2 = res_unit(self.part2_1_2, self.part2_1_1(xb, dx_put=fb))
         x2 = self.part2_2(x2, out=cb.slot(0))
         return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)
 
@@ -242,7 +255,8 @@ class CSPDownSample(nn.Module):
         both = soft(bool(_TWIN_RES and takes_planes(self.part1) and takes_planes(self.part2[0])), self.part1, self.part2, self.part2[0])
         xa, xb = ops.fork(self.base(x, out_planes=both))
         cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels])
-        x1 = self.part1(xa, out=cb.slot(1))
+        fb = None if observed(self.part2) else fork_box(xa, self.part1, self.part2[0])
+        x1 = self.part1(xa, out=cb.slot(1), dres_take=fb)
         if observed(self.part2):
             x2 = self.part2(xb)                      # hooks on the Sequential: the plain call; cat copies its result in
             return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)
@@ -250,6 +264,6 @@ class CSPDownSample(nn.Module):
         # part2[0]'s result feeds the first unit's 1x1 conv and its skip; the block's result feeds part2[2] alone
         first = 'both' if (blk.shortcut and blk.first_takes_planes()) else False
         last = soft(bool(blk.shortcut and _TWIN_RES and takes_planes(self.part2[2])), blk, self.part2[2])
-        x2 = blk(self.part2[0](xb, out_planes=first), out_planes=last)
+        x2 = blk(self.part2[0](xb, out_planes=first, dx_put=fb), out_planes=last)
         x2 = self.part2[2](x2, out=cb.slot(0))
         return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)

@@ -802,7 +802,7 @@ class ConvBNActFn(torch.autograd.Function):
         # scalars and parameter handles backward needs, nothing else.
         dest = cfg.pop('out', None)
         ctx.cfg = {key: cfg.get(key) for key in ('k', 's', 'act', 'gamma_param', 'beta_param', 'weight_param',
-                                                 'dres_put', 'dres_take')}
+                                                 'dres_put', 'dres_take', 'dx_put')}
         ctx.x_shape = tuple(x.shape)
         ctx.has_res = residual is not None
         # conv mode 3: operand maxima travel with the tensors (see "operand maxima" above)
@@ -956,6 +956,8 @@ class ConvBNActFn(torch.autograd.Function):
         dx = None
         take = cfg.get('dres_take')
         skip_grad = take.pop('dres', None) if take is not None else None
+        if take is not None and skip_grad is None:
+            take['taker_done'] = True                # (a fork box whose other branch has not run yet: it must not park any more)
         if ctx.needs_input_grad[0]:
             if ctx.x_shape[1] == 3 and k == 3 and s == 1 and weight.shape[0] <= 32 and skip_grad is None:
                 dx = conv_stem_dgrad_raw(dy, weight, x)       # gradient wrt the network input (never needed in training)
@@ -970,6 +972,12 @@ class ConvBNActFn(torch.autograd.Function):
             ctx.dgrad_filter = None
         elif skip_grad is not None:
             raise Y4Error('a parked skip gradient has no consumer (input of the 1x1 conv does not require grad)')
+        # dx_put: this conv and another one read the same tensor (a CSP fork); whichever backward runs first parks its dx here,
+        # the other adds it in its dgrad epilogue (dres_take) -- the fork's fan-in add costs one operand read instead of a pass
+        fbox = cfg.get('dx_put')
+        if fbox is not None and dx is not None and not fbox.get('taker_done'):
+            fbox['dres'] = dx
+            dx = None
         dw = None
         if ctx.needs_input_grad[1]:
             param = cfg.get('weight_param')
