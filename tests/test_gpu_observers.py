@@ -144,3 +144,42 @@ def test_pre_split_tensor_refuses_to_be_read_as_numbers(dev, tmp_path):
     c = ConvBNAct(128, 128, 3, 1).to(dev).train()
     c(z).sum().backward()
     assert m.conv.weight.grad is not None and bool(torch.isfinite(m.conv.weight.grad).all())
+
+
+@pytest.mark.parametrize('stage', ['stage1', 'stage3'])
+def test_csp_fork_fan_in_folded_into_the_dgrad_epilogue(dev, stage):
+    """The gradient fan-in of a CSP fork (darknet._FORK_FOLD): the split conv whose backward runs first parks its dx, the other
+    adds it as the skip operand of its dgrad -- same sums as the separate add pass (one fp32 addition per element either way),
+    for the streaming 1x1 kernels (stage 1) and the plane kernels (stage 3); and a hook on one of the two convs switches it off."""
+    from yolov4_amd.darknet import darknet as D
+    torch.manual_seed(9)
+    blk = (D.CSPDownSample0(32, 64, 3, 2) if stage == 'stage1' else D.CSPDownSample(128, 256, 3, 2, num_blocks=2)).to(dev).train()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+    cin, S = (32, 208) if stage == 'stage1' else (128, 40)
+    x = torch.randn(2, cin, S, S, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(2, blk.transition.conv.out_channels, S // 2, S // 2, device=dev).contiguous(memory_format=torch.channels_last)
+
+    def run(fold):
+        D._FORK_FOLD = fold
+        for p in blk.parameters():
+            p.grad = None
+        x.grad = None
+        (blk(x) * w).sum().backward()
+        torch.cuda.synchronize()
+        return x.grad.clone(), [p.grad.clone() for p in blk.parameters()]
+    was = D._FORK_FOLD
+    try:
+        gx1, gp1 = run(True)
+        gx0, gp0 = run(False)
+        h = blk.part1.register_forward_hook(lambda m, i, o: None)
+        gxh, _ = run(True)                              # observed: no box, autograd's own fan-in
+        h.remove()
+    finally:
+        D._FORK_FOLD = was
+    assert float((gx1 - gx0).abs().max()) <= 2e-5 * float(gx0.abs().max())
+    assert torch.equal(gxh, gx0)
+    for a, b in zip(gp1, gp0):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6)
