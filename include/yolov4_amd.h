@@ -74,6 +74,12 @@ int y4_get_conv_mode(void);
  * layer keeps the fp32-grade f16x2 kernels of mode 3, which are HBM-bound anyway.  (Mode 2 rounds EVERY conv operand to bf16.) */
 int y4_set_planes_bf16(int on);
 int y4_get_planes_bf16(void);
+/* 1 if EVERY plane kernel a conv layer of this geometry (x: [B][H][W][Cin]; k in {1,3}; stride 1, or 2 with k = 3 on an even
+ * grid) would launch in the current mode can address its operands -- the DMA kernels use 32-bit buffer windows (an image span
+ * of a 256-row tile, a wgrad block's pixel range, the whole dx of a stride-2 dgrad: each < 4 GiB) -- else 0.  dgrad_planes: the
+ * layer's dgrad runs on the plane kernels too.  The host asks this before it lets a producer write its result pre-split: such
+ * an operand has no fp32 form for the register-staged kernels to fall back to (yolov4_amd/darknet/darknet.py takes_planes()). */
+int y4_conv_planes_fit(int B, int H, int W, int Cin, int Cout, int k, int stride, int dgrad_planes);
 /* ---------------------------------------------------------------- convolution
  * Replaces nn.Conv2d inside ConvBNAct.forward, darknet/darknet.py:31-36,53-54
  * (k in {1,3}, stride in {1,2}, pad=(k-1)//2, dilation 1, groups 1).

@@ -54,6 +54,27 @@ def test_workspace_queries_run_on_host():
     assert L.y4_post_nms_workspace(1000, 160) >= 1000 * (8 + 16 + 4 + 4)
 
 
+def test_plane_window_query_runs_on_host():
+    """y4_conv_planes_fit: the DMA kernels' 32-bit buffer windows, asked by the host before a producer writes planes."""
+    L = yolov4_amd.lib()
+    was = L.y4_get_conv_mode()
+    try:
+        L.y4_set_conv_mode(3)
+        assert L.y4_conv_planes_fit(64, 76, 76, 128, 128, 3, 1, 1) == 1
+        assert L.y4_conv_planes_fit(64, 152, 152, 128, 256, 3, 2, 1) == 1
+        assert L.y4_conv_planes_fit(64, 76, 76, 100, 128, 3, 1, 1) == 0            # not whole K tiles
+        assert L.y4_conv_planes_fit(64, 75, 76, 128, 256, 3, 2, 1) == 0            # stride 2 on an odd grid
+        assert L.y4_conv_planes_fit(1, 4096, 4096, 64, 128, 3, 1, 1) == 0          # one image = 4 GiB: beyond a forward window
+        assert L.y4_conv_planes_fit(1, 1024, 1024, 64, 128, 3, 1, 1) == 1
+        # stride 2: the plane dgrad scatters into ONE window over the whole dx tensor (6 GiB here); forward and wgrad fit
+        assert L.y4_conv_planes_fit(512, 152, 152, 128, 256, 3, 2, 1) == 0
+        assert L.y4_conv_planes_fit(512, 152, 152, 128, 256, 3, 2, 0) == 1
+        L.y4_set_conv_mode(0)
+        assert L.y4_conv_planes_fit(64, 76, 76, 128, 128, 3, 1, 1) == 0            # no plane kernels in this mode
+    finally:
+        L.y4_set_conv_mode(was)
+
+
 def test_null_and_shape_errors_are_reported_before_any_launch():
     L = yolov4_amd.lib()
     assert L.y4_conv2d_fwd_f32(None, 32, None, None, 32, 1, 8, 8, 32, 32, 3, 1, None, None, 0, None, 0, None, None, None, 0, None) == 2

@@ -406,6 +406,9 @@ def test_stride2_module_through_planes_matches_the_fp32_tensor_path(dev):
     x = torch.randn(3, 128, 20, 20, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     wgt = torch.randn(3, 128, 10, 10, device=dev).contiguous(memory_format=torch.channels_last)
     assert takes_planes(b, (20, 20)) and not takes_planes(b, (19, 19)) and not takes_planes(b)
+    # ... and never where an operand would be beyond the kernels' 32-bit windows (one 64-channel image of 4096 x 4096 = 4 GiB)
+    assert takes_planes(a, geo=(3, 20, 20)) and not takes_planes(a, geo=(1, 8192, 8192))
+    assert takes_planes(b, (20, 20), (3, 20, 20)) and plan_for([b], (8192, 8192), 1) is False
     kinds = []
 
     def run(on):

@@ -31,6 +31,7 @@ PROTOTYPES = {
     'y4_get_conv_mode': (I, []),
     'y4_set_planes_bf16': (I, [I]),
     'y4_get_planes_bf16': (I, []),
+    'y4_conv_planes_fit': (I, [I, I, I, I, I, I, I, I]),
     'y4_conv2d_fwd_workspace': (Z, [I, I, I]),
     'y4_conv2d_fwd_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, P, I, P, I, P, P, P, Z, P]),
     'y4_amax_f32': (I, [P, I, L, I, P, P]),

@@ -876,6 +876,49 @@ bool planes_conv_ok(int Cin, int Cout, int k, int stride) {
     return Cin > 0 && (Cin & 31) == 0 && Cout > 0 && (Cout & 3) == 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2);
 }
 
+// The DMA kernels address their operands through 32-bit buffer windows.  One predicate per kernel family, used by the launchers
+// below AND by y4_conv_planes_fit (the host asks BEFORE it lets a producer emit planes: an operand that exists only pre-split
+// has no register-staged kernel to fall back to).
+// forward form: the window starts at the first image a 256-row tile touches
+static bool conv_window_ok(int B, int Hs, int Ws, int Cs, int N, int k, int stride, bool bf) {
+    const int pad = (k - 1) / 2;
+    const long long Hd = (Hs + 2 * pad - k) / stride + 1, Wd = (Ws + 2 * pad - k) / stride + 1;
+    if (Hd <= 0 || Wd <= 0 || (long long)B * Hd * Wd >= (1ll << 31)) return false;
+    const unsigned long long img = (unsigned long long)Hs * Ws * (unsigned long long)Cs * 4ull;
+    const unsigned long long wb = (unsigned long long)N * k * k * Cs * (bf ? 2ull : 4ull);
+    const unsigned long long imgs_per_tile = 256ull / (unsigned long long)(Hd * Wd) + 2;
+    return img * imgs_per_tile < 0xfffffff0ull && wb < 0xfffffff0ull;
+}
+// stride-2 dgrad: the parity-class launches scatter into one window over the whole dx tensor
+static bool dgrad_s2_window_ok(int B, int H, int W, int Cin, int Cout, long long lddx) {
+    if ((H & 1) || (W & 1)) return false;
+    return conv_window_ok(B, H / 2, W / 2, Cout, Cin, 3, 1, false) &&
+           (unsigned long long)B * H * W * (unsigned long long)lddx * 4ull < 0xfffffff0ull;
+}
+// wgrad (H, W: the dy grid): a block's windows cover its K range plus the taps' reach
+static bool wgrad_window_ok(int B, int H, int W, int Cin, int Cout, int k, int stride, bool bf) {
+    const long long M = (long long)B * H * W;
+    if (M >= (1ll << 31) - 65536) return false;            // (32-bit pixel counters in the kernel, with room for a K-step past M)
+    if ((unsigned long long)Cout * k * k * Cin * 4ull >= 0xfffffff0ull) return false;
+    int ntn, ntj, splits, sps;
+    planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps, planes_wgrad_tn(Cout, bf));
+    const int pad = (k - 1) / 2;
+    const unsigned long long range_px = (unsigned long long)sps * 32ull + 2ull * (unsigned long long)(pad * W + pad) + 64ull;
+    const unsigned long long range_x = stride == 1 ? range_px : 4ull * range_px + 8ull * (unsigned long long)W + 64ull;
+    return range_px * (unsigned long long)Cout * 4ull < 0xfffffff0ull && range_x * (unsigned long long)Cin * 4ull < 0xfffffff0ull;
+}
+// every plane kernel a ConvBNAct layer with this geometry would launch (x: [B][H][W][Cin]); dgrad_planes: its dgrad too
+bool planes_fit(int B, int H, int W, int Cin, int Cout, int k, int stride, bool bf, bool dgrad_planes) {
+    if (B <= 0 || H <= 0 || W <= 0 || !planes_conv_ok(Cin, Cout, k, stride) || (Cout & 31)) return false;
+    if (stride == 2 && (k != 3 || (H & 1) || (W & 1))) return false;
+    if (!conv_window_ok(B, H, W, Cin, Cout, k, stride, bf)) return false;
+    const int Ho = H / stride, Wo = W / stride;
+    if (dgrad_planes) {
+        if (stride == 1 ? !conv_window_ok(B, H, W, Cout, Cin, k, 1, bf) : !dgrad_s2_window_ok(B, H, W, Cin, Cout, Cin)) return false;
+    }
+    return wgrad_window_ok(B, Ho, Wo, Cin, Cout, k, stride, bf);
+}
+
 // forward-form conv over planes: src [B][Hs][Ws][Cs] planes, filter planes [N][k*k*Cs], raw fp32 result (+ res) and
 // optional per-M-tile column sums (256-row tiles).  bf: plain bf16 operands (conv mode 2), amax words unused.
 int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes, const unsigned* wt_amax, float* dst, long long ldd,
@@ -890,15 +933,12 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
     g.B = B; g.Hs = Hs; g.Ws = Ws; g.Cs = Cs; g.N = N; g.k = k; g.stride = stride; g.pad = pad;
     g.Hd = (Hs + 2 * pad - k) / stride + 1;
     g.Wd = (Ws + 2 * pad - k) / stride + 1;
+    if (!conv_window_ok(B, Hs, Ws, Cs, N, k, stride, bf)) return Y4_ERR_SHAPE;
     const long long M = (long long)B * g.Hd * g.Wd;
-    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     if (bf && (Cs & 63)) return Y4_ERR_SHAPE;              // whole 64-channel K tiles
     g.M = (int)M; g.K = k * k * Cs;
     const unsigned long long img = (unsigned long long)Hs * Ws * (unsigned long long)Cs * 4ull;
     const unsigned long long wb = (unsigned long long)N * g.K * (bf ? 2ull : 4ull);
-    // a 256-row tile may span several images: the 32-bit window starts at the first one
-    const unsigned long long imgs_per_tile = 256ull / (unsigned long long)(g.Hd * g.Wd > 0 ? g.Hd * g.Wd : 1) + 2;
-    if (img * imgs_per_tile >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;
     g.src_total_bytes = (unsigned long long)B * img;
     g.wt_bytes = (unsigned)wb;
     g.src_amax = src_amax; g.wt_amax = wt_amax;
@@ -949,14 +989,11 @@ int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_plan
     g.dst = dx; g.ldd = lddx;
     g.B = B; g.Hs = Ho; g.Ws = Wo; g.Cs = Cout; g.N = Cin; g.k = 3; g.stride = 1; g.pad = 0;
     g.Hd = Ho; g.Wd = Wo; g.Hfull = H; g.Wfull = W;
+    if (B <= 0 || Ho <= 0 || Wo <= 0 || !dgrad_s2_window_ok(B, H, W, Cin, Cout, lddx)) return Y4_ERR_SHAPE;
     const long long M = (long long)B * Ho * Wo;
-    if (M >= (1ll << 31)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.K = 9 * Cout;
     const unsigned long long img = (unsigned long long)Ho * Wo * (unsigned long long)Cout * 4ull;
     const unsigned long long wb = (unsigned long long)Cin * g.K * 4ull;
-    const unsigned long long imgs_per_tile = 256ull / (unsigned long long)(Ho * Wo > 0 ? Ho * Wo : 1) + 2;
-    if (img * imgs_per_tile >= 0xfffffff0ull || wb >= 0xfffffff0ull) return Y4_ERR_SHAPE;
-    if ((unsigned long long)B * H * W * (unsigned long long)lddx * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
     g.src_total_bytes = (unsigned long long)B * img;
     g.wt_bytes = (unsigned)wb;
     g.src_amax = dy_amax; g.wt_amax = wt_amax;
@@ -1031,18 +1068,13 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     } else if (stride != 1) return Y4_ERR_SHAPE;
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.pad = (k - 1) / 2;
     const long long M = (long long)B * H * W;
-    if (M >= (1ll << 31) - 65536) return Y4_ERR_SHAPE;     // (32-bit pixel counters in the kernel, with room for a K-step past M)
     if (bf && ((Cin & 63) || (Cout & 63))) return Y4_ERR_SHAPE;
+    if (!wgrad_window_ok(B, H, W, Cin, Cout, k, stride, bf)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.J = k * k * Cin;
-    if ((unsigned long long)Cout * g.J * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
     const int tn = planes_wgrad_tn(Cout, bf);
     planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split, tn);
     g.x_total_bytes = (unsigned long long)M * stride * stride * Cin * 4ull;
     g.dy_total_bytes = (unsigned long long)M * Cout * 4ull;
-    // a block's 32-bit windows: its K range + the taps' reach (x pixels: stride^2 per dy pixel)
-    const unsigned long long range_px = (unsigned long long)g.steps_per_split * 32ull + 2ull * (unsigned long long)(g.pad * W + g.pad) + 64ull;
-    const unsigned long long range_x = stride == 1 ? range_px : 4ull * range_px + 8ull * (unsigned long long)W + 64ull;
-    if (range_px * (unsigned long long)Cout * 4ull >= 0xfffffff0ull || range_x * (unsigned long long)Cin * 4ull >= 0xfffffff0ull) return Y4_ERR_SHAPE;
     g.x_amax = x_amax; g.dy_amax = dy_amax;
     const size_t slab = (size_t)Cout * g.J * sizeof(float);
     if (g.splits > 1) {
@@ -1087,6 +1119,12 @@ static inline bool pl_bf() { const int m = y4_get_conv_mode(); return m == 2 || 
 extern "C" {
 
 int y4_set_planes_bf16(int on) { g_planes_bf16 = on ? 1 : 0; return Y4_OK; }
+int y4_conv_planes_fit(int B, int H, int W, int Cin, int Cout, int k, int stride, int dgrad_planes) {
+    if (!pl_mode_ok()) return 0;
+    const bool bf = pl_bf();
+    if (bf && ((Cin & 63) || (Cout & 63))) return 0;
+    return y4::planes_fit(B, H, W, Cin, Cout, k, stride, bf, dgrad_planes != 0) ? 1 : 0;
+}
 int y4_get_planes_bf16(void) { return g_planes_bf16; }
 
 int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, void* stream) {

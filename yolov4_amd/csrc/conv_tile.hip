@@ -375,11 +375,17 @@ namespace y4 {
 
 // 3x3 / stride 1 / pad 1, 32 or 64 gathered channels, <= 64 produced channels, a map large enough that the gather kernel's
 // nine-fold staging is what bounds it, and nothing in the epilogue but the raw result (+ residual, + column sums)
+// The kernels address one image of each tensor through a 32-bit window (H * W * pitch * 4 B < 4 GiB).  The predicates below
+// are asked where the pitches are not known yet (the forward call prepares the dgrad filter in the form THIS dgrad kernel wants),
+// so they assume the widest pitch a tile layer meets in a cat buffer, 256 channels: larger maps (> 2047 x 2047) go to the gather
+// kernels, whose addresses are 64-bit.  (The launchers keep the exact test for callers with wider pitches.)
+static bool tile_window_ok(long long H, long long W) { return (unsigned long long)(H * W) * 4ull * 256ull < 0xfffffff0ull; }
+
 bool tile_conv_ok(int Cs, int Cs_valid, int N, int k, int stride, int H, int W) {
     static const bool off = getenv("Y4_NO_TILE") != nullptr;
     if (off || k != 3 || stride != 1 || Cs != Cs_valid || (Cs != 32 && Cs != 64) || N < 1 || N > 64) return false;
     if ((long long)H * W < 100 * 100) return false;
-    return true;
+    return tile_window_ok(H, W);
 }
 
 int f16x2_tile(const ConvGeom& g, hipStream_t st, int* nparts) {
@@ -396,7 +402,8 @@ int f16x2_tile(const ConvGeom& g, hipStream_t st, int* nparts) {
 // gathered tensor is dy ([B][Hs][Ws][64]), the produced one dx ([B][Hd][Wd][N]); filter planes transposed, NOT mirrored
 bool tile_dgrad_s2_ok(int Cs, int Cs_valid, int N, int k, int stride, int Hs, int Ws) {
     static const bool off = getenv("Y4_NO_TILE") != nullptr;
-    return !off && k == 3 && stride == 2 && Cs == 64 && Cs_valid == 64 && N >= 1 && N <= 32 && (long long)Hs * Ws >= 100 * 100;
+    return !off && k == 3 && stride == 2 && Cs == 64 && Cs_valid == 64 && N >= 1 && N <= 32 && (long long)Hs * Ws >= 100 * 100 &&
+           tile_window_ok(2ll * Hs, 2ll * Ws);            // (dx lives on the 2 Hs x 2 Ws grid)
 }
 
 int f16x2_tile_dgrad_s2(const ConvGeom& g, hipStream_t st) {

@@ -64,7 +64,7 @@ class ConvBNAct(nn.Module):
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
                'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes, 'dx_put': dx_put,
-               'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self, x.shape[2:]) else None,
+               'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self, x.shape[2:], geo_of(x)) else None,
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:
             use_batch_stats = self.training or n.running_mean is None
@@ -115,13 +115,17 @@ def soft(want, *mods):
     return 'both' if (want is True and observed(*mods)) else want
 
 
-def takes_planes(m, hw=None):
+def takes_planes(m, hw=None, geo=None):
     """True if ConvBNAct `m` can consume a pre-split (planes) input right now: training-mode BatchNorm, conv mode 3 (or 2),
     whole 32-channel K tiles on both sides and at least one full 128-column tile of output channels; stride 1 (all three
     of its convs then run on the DMA kernels of csrc/conv_planes.hip), or a 3x3 stride-2 layer on an even map `hw` = (H, W)
-    of its input (forward and wgrad on the DMA kernels, dgrad on the register-staged parity-class kernel)."""
+    of its input (forward and wgrad on the DMA kernels, dgrad on the register-staged parity-class kernel).
+    geo = (B, H, W) of its input, where the caller knows it: the operands must also fit the kernels' 32-bit buffer windows
+    (ops.planes_fit) -- a producer must never emit planes its consumer cannot address, there is no fp32 form to fall back to."""
     if not isinstance(m, ConvBNAct) or not m.has_bn or not m.training:
         return False
+    if geo is not None and hw is None and m.stride == 1:
+        hw = geo[1:]
     if m.stride != 1 and not (hw is not None and ops.planes_stride2_ok(m.kernel_size, m.stride, int(hw[0]), int(hw[1]))):
         return False
     ci, co = m.conv.in_channels, m.conv.out_channels
@@ -130,13 +134,23 @@ def takes_planes(m, hw=None):
     if not (ops.PLANES['on'] and m.conv.weight.is_cuda):
         return False
     pm = ops.planes_mode()
-    return pm == 'f16x2' or (pm == 'bf16' and ci % 64 == 0 and co % 64 == 0)     # bf16 rows hold 64 channels
+    if not (pm == 'f16x2' or (pm == 'bf16' and ci % 64 == 0 and co % 64 == 0)):  # bf16 rows hold 64 channels
+        return False
+    # stride 2: backward picks the register-staged dgrad by itself when the plane one does not fit (ConvBNActFn.backward)
+    return geo is None or ops.planes_fit(geo[0], geo[1], geo[2], ci, co, m.kernel_size, m.stride, dgrad=m.stride == 1)
 
 
-def plan_for(consumers, hw):
-    """out_planes request for a tensor of spatial size hw read by the ConvBNAct modules `consumers`: True if its single reader
-    takes planes, 'both' if one of several does (or somebody is looking), else False."""
-    takers = [m for m in consumers if takes_planes(m, hw)]
+def geo_of(x, after=None):
+    """(B, H, W) of NCHW tensor x, or of the result of ConvBNAct `after` applied to it."""
+    st = after.stride if isinstance(after, ConvBNAct) else 1
+    return (int(x.shape[0]), -(-int(x.shape[2]) // st), -(-int(x.shape[3]) // st))      # (k = 3, pad 1 or k = 1: ceil)
+
+
+def plan_for(consumers, hw, batch=None):
+    """out_planes request for a tensor of spatial size hw (batch size `batch`) read by the ConvBNAct modules `consumers`: True if
+    its single reader takes planes, 'both' if one of several does (or somebody is looking), else False."""
+    geo = (int(batch), int(hw[0]), int(hw[1])) if batch is not None else None
+    takers = [m for m in consumers if takes_planes(m, hw, geo)]
     if not takers:
         return False
     if len(consumers) == 1:
@@ -153,7 +167,7 @@ def chain(seq, x, last=False):
     mods = list(seq)
     for i, m in enumerate(mods):
         nxt = mods[i + 1] if i + 1 < len(mods) else None
-        want = soft(takes_planes(nxt), nxt) if nxt is not None else last
+        want = soft(takes_planes(nxt, geo=geo_of(x, m)), nxt) if nxt is not None else last
         x = m(x, out_planes=want) if isinstance(m, ConvBNAct) else m(x)
     return x
 
@@ -166,7 +180,7 @@ def res_unit(pair, x, out_planes=False):
     if observed(pair):
         return ops.AddFn.apply(xb, pair(xa))         # hooks on the pair: the reference's x + module(x), unfused
     box = {} if (torch.is_grad_enabled() and xa.requires_grad and pair[0].training) else None
-    return pair[1](pair[0](xa, dres_take=box, out_planes=soft(takes_planes(pair[1]), pair[1])), residual=xb, dres_put=box,
+    return pair[1](pair[0](xa, dres_take=box, out_planes=soft(takes_planes(pair[1], geo=geo_of(xa)), pair[1])), residual=xb, dres_put=box,
                    out_planes=out_planes)
 
 
@@ -202,7 +216,7 @@ class ResBlock(nn.Module):
         for i, pair in enumerate(self.module_list):
             if self.shortcut:
                 if i + 1 < n:
-                    want = 'both' if (_TWIN_RES and takes_planes(self.module_list[i + 1][0])) else False
+                    want = 'both' if (_TWIN_RES and takes_planes(self.module_list[i + 1][0], geo=geo_of(x))) else False
                 else:
                     want = soft(out_planes, self)
                 x = res_unit(pair, x, out_planes=want)
@@ -210,8 +224,8 @@ class ResBlock(nn.Module):
                 x = pair[1](pair[0](x))
         return x
 
-    def first_takes_planes(self):
-        return _TWIN_RES and takes_planes(self.module_list[0][0])
+    def first_takes_planes(self, geo=None):
+        return _TWIN_RES and takes_planes(self.module_list[0][0], geo=geo)
 
 
 class CSPDownSample0(nn.Module):
@@ -235,7 +249,7 @@ class CSPDownSample0(nn.Module):
         x1 = self.part1(xa, out=cb.slot(1), dres_take=fb)
         x2 = res_unit(self.part2_1_2, self.part2_1_1(xb, dx_put=fb))
         x2 = self.part2_2(x2, out=cb.slot(0))
-        return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)
+        return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:], xa.shape[0]), self) if readers else False)
 
 
 class CSPDownSample(nn.Module):
@@ -252,18 +266,20 @@ class CSPDownSample(nn.Module):
     def forward(self, x, readers=None):
         """readers: as CSPDownSample0.forward."""
         # both consumers of the stride-2 conv's result are 1x1 convs: where both take planes the result leaves pre-split only
-        both = soft(bool(_TWIN_RES and takes_planes(self.part1) and takes_planes(self.part2[0])), self.part1, self.part2, self.part2[0])
+        go = geo_of(x, self.base)
+        both = soft(bool(_TWIN_RES and takes_planes(self.part1, geo=go) and takes_planes(self.part2[0], geo=go)),
+                    self.part1, self.part2, self.part2[0])
         xa, xb = ops.fork(self.base(x, out_planes=both))
         cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels])
         fb = None if observed(self.part2) else fork_box(xa, self.part1, self.part2[0])
         x1 = self.part1(xa, out=cb.slot(1), dres_take=fb)
         if observed(self.part2):
             x2 = self.part2(xb)                      # hooks on the Sequential: the plain call; cat copies its result in
-            return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)
+            return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:], xa.shape[0]), self) if readers else False)
         blk = self.part2[1]
         # part2[0]'s result feeds the first unit's 1x1 conv and its skip; the block's result feeds part2[2] alone
-        first = 'both' if (blk.shortcut and blk.first_takes_planes()) else False
-        last = soft(bool(blk.shortcut and _TWIN_RES and takes_planes(self.part2[2])), blk, self.part2[2])
+        first = 'both' if (blk.shortcut and blk.first_takes_planes(go)) else False
+        last = soft(bool(blk.shortcut and _TWIN_RES and takes_planes(self.part2[2], geo=go)), blk, self.part2[2])
         x2 = blk(self.part2[0](xb, out_planes=first, dx_put=fb), out_planes=last)
         x2 = self.part2[2](x2, out=cb.slot(0))
-        return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:]), self) if readers else False)
+        return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:], xa.shape[0]), self) if readers else False)

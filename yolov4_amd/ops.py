@@ -11,6 +11,7 @@ NHWC (torch.channels_last), possibly a channel slice of a wider NHWC buffer
 state_dict layout, darknet/darknet.py:31-36) stored channels_last == KRSC.
 """
 import ctypes
+import functools
 import os
 
 import torch
@@ -236,6 +237,19 @@ def planes_stride2_ok(k, s, H, W):
     # (bf16 operands: only in the hybrid mode, whose register-staged stride-2 dgrad is the f16x2 one; mode 2 keeps stride 2 off planes)
     return (s == 2 and k == 3 and H % 2 == 0 and W % 2 == 0 and _S2_PLANES
             and (planes_mode() == 'f16x2' or (planes_mode() == 'bf16' and f16x2_mode())))
+
+
+@functools.lru_cache(maxsize=4096)
+def _planes_fit(mode, B, H, W, ci, co, k, s, dgrad):
+    return bool(lib().y4_conv_planes_fit(B, H, W, ci, co, k, s, 1 if dgrad else 0))
+
+
+def planes_fit(B, H, W, ci, co, k, s, dgrad=True):
+    """Can the DMA kernels address every operand of this layer (32-bit buffer windows, y4_conv_planes_fit)?  Asked BEFORE a
+    producer is told to write its result pre-split, and before backward picks the plane dgrad of a stride-2 layer: a tensor
+    that exists only as planes has no register-staged kernel to fall back to."""
+    return _planes_fit((lib().y4_get_conv_mode(), lib().y4_get_planes_bf16()), int(B), int(H), int(W), int(ci), int(co),
+                       int(k), int(s), bool(dgrad))
 
 
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
@@ -930,7 +944,10 @@ class ConvBNActFn(torch.autograd.Function):
             # wants fp32 -- dy leaves the sweep both ways (the bound in word [5] dominates max|dy|: it serves both as scale)
             # (f16x2 operands: the plane kernel runs the stride-2 dgrad too, class by class -- no fp32 copy)
             # and not with fewer than 128 input channels (half-empty column tiles: 64->128 @304 took 1.81 ms there, 1.24 + 0.14 this way)
-            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and (bfp or not _S2_DGRAD_PLANES or ctx.x_shape[1] < 128)
+            # nor when the whole dx tensor is beyond the plane dgrad's one 32-bit window (planes_fit)
+            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and (
+                bfp or not _S2_DGRAD_PLANES or ctx.x_shape[1] < 128
+                or not planes_fit(ctx.x_shape[0], ctx.x_shape[2], ctx.x_shape[3], ctx.x_shape[1], dz.shape[1], k, s, dgrad=True))
             res = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                  gp.grad if sink else None, bp.grad if sink else None,
                                  out_amax=None if planes is not None else dy_amax, planes=planes,

@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from ... import ops
-from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain, observed, plan_for, soft, takes_planes
+from ...darknet.darknet import ConvBNAct, CSPDownSample0, CSPDownSample, chain, geo_of, observed, plan_for, soft, takes_planes
 from .yololayer import YOLOLayer
 
 L = 'leaky_relu'
@@ -142,7 +142,7 @@ class PANBlock(nn.Module):
         p2 = self.conv1(f1b, out=cb.slot(0))
         assert p2.shape[2:] == f2.shape[2:]
         p2 = chain(self.module1, ops.cat([p2, f2], into=cb),
-                   last='both' if (head_planes[0] or takes_planes(self.conv7, p2.shape[2:])) else False)
+                   last='both' if (head_planes[0] or takes_planes(self.conv7, p2.shape[2:], geo_of(p2))) else False)
         p2a, p2b = ops.fork(p2)
         cb = ops.cat_buffer(f3, [512, f3.shape[1]])
         p3 = self.conv7(p2a, out=cb.slot(0))
@@ -161,9 +161,9 @@ class Neck(nn.Module):
 
     def forward(self, x3, x4, x5, head_planes=(False, False, False)):
         """head_planes: which of the three head 3x3 convs take pre-split inputs (YOLOv4.forward asks them)."""
-        x5 = self.spp(x5, out_planes=soft(takes_planes(self.fpn.module1[0]), self.fpn, self.fpn.module1, self.fpn.module1[0]))
+        x5 = self.spp(x5, out_planes=soft(takes_planes(self.fpn.module1[0], geo=geo_of(x5)), self.fpn, self.fpn.module1, self.fpn.module1[0]))
         # f1 is read by head.yolo1[0] and by the stride-2 conv pan.conv1: either taking planes asks for the pre-split twin
-        f1_twin = head_planes[0] or takes_planes(self.pan.conv1, x3.shape[2:])
+        f1_twin = head_planes[0] or takes_planes(self.pan.conv1, x3.shape[2:], geo_of(x3))
         return self.pan(*self.fpn(x3, x4, x5, head_planes=f1_twin), head_planes=head_planes[1:])
 
 
@@ -222,8 +222,9 @@ class YOLOv4(nn.Module):
         if x.dtype != torch.float32:
             x = x.float()              # Transform hands float64 images; apex O0 casts them
         # (True: the head conv may be the SOLE reader of a pre-split tensor; 'both' where somebody may be looking on the way)
-        hp = tuple(soft(takes_planes(h[0]), self.neck, self.neck.pan, self.head, h, h[0])
-                   for h in (self.head.yolo1, self.head.yolo2, self.head.yolo3))
+        B, H, W = geo_of(x)                      # the three heads read maps of stride 8 / 16 / 32
+        hp = tuple(soft(takes_planes(h[0], geo=(B, -(-H // st), -(-W // st))), self.neck, self.neck.pan, self.head, h, h[0])
+                   for h, st in ((self.head.yolo1, 8), (self.head.yolo2, 16), (self.head.yolo3, 32)))
         # who reads the backbone's three results: fpn.conv11 (x3), fpn.conv4 (x4), the first conv of the SPP block (x5, alone)
         seen = observed(self.backbone, self.neck, self.neck.spp, self.neck.spp.conv1, self.neck.fpn)
         readers = ((self.neck.fpn.conv11,), (self.neck.fpn.conv4,), () if seen else (self.neck.spp.conv1[0],))
