@@ -41,15 +41,16 @@ __device__ __forceinline__ float y4_mish(float x) {
     const float w = n * (n + 2.0f);
     return x * (w * __frcp_rn(w + 2.0f));
 }
-// d/dx [x * t(x)], t = tanh(softplus(x)):  t + x * (1 - t^2) * sigmoid(x)
+// d/dx [x * t(x)], t = tanh(softplus(x)):  t + x * (1 - t^2) * sigmoid(x).  With w = n(n + 2), d = w + 2:
+// t = w / d, 1 - t^2 = 4 (w + 1) / d^2 = 4 (n + 1)^2 / d^2, sigmoid = n / (n + 1)  =>  (1 - t^2) sigmoid = 4 n (n + 1) / d^2,
+// so the derivative is (w + 4 x n (n + 1) / d) / d: ONE v_rcp_f32 beside the v_exp_f32 (no cancellation: every term but x
+// is positive).  The BatchNorm backward sweeps evaluate this twice per element and run close to the VALU rate with it.
 __device__ __forceinline__ float y4_mish_grad(float x) {
     const float n = __expf(fminf(x, 20.0f));
     const float w = n * (n + 2.0f);
     const float rd = __frcp_rn(w + 2.0f);
-    const float t = w * rd;
-    const float omt2 = 4.0f * (w + 1.0f) * rd * rd;      // 1 - t^2 without cancellation
-    const float sg = n * __frcp_rn(1.0f + n);
-    return t + x * omt2 * sg;
+    const float q = fmaf(n, n, n);                         // n (n + 1)
+    return fmaf(4.0f * (x * q), rd, w) * rd;
 }
 __device__ __forceinline__ float y4_act(float x, int act) {
     switch (act) {
@@ -66,6 +67,20 @@ __device__ __forceinline__ float y4_act_grad(float x, int act) {
         case Y4_ACT_RELU: return x > 0.0f ? 1.0f : 0.0f;
         default: return 1.0f;
     }
+}
+
+// the same with the activation a compile-time constant (the BatchNorm sweeps: no branch per element, full unrolling)
+template <int ACT> __device__ __forceinline__ float y4_act_t(float x) {
+    if constexpr (ACT == Y4_ACT_LEAKY) return x > 0.0f ? x : 0.1f * x;
+    else if constexpr (ACT == Y4_ACT_MISH) return y4_mish(x);
+    else if constexpr (ACT == Y4_ACT_RELU) return fmaxf(x, 0.0f);
+    else return x;
+}
+template <int ACT> __device__ __forceinline__ float y4_act_grad_t(float x) {
+    if constexpr (ACT == Y4_ACT_LEAKY) return x > 0.0f ? 1.0f : 0.1f;
+    else if constexpr (ACT == Y4_ACT_MISH) return y4_mish_grad(x);
+    else if constexpr (ACT == Y4_ACT_RELU) return x > 0.0f ? 1.0f : 0.0f;
+    else return 1.0f;
 }
 
 // XCD-aware block remap (MI355X: 8 XCDs, blocks dealt round-robin, private L2 each): give every

@@ -1129,6 +1129,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_f16x2
         const unsigned off = m < g.M ? (unsigned)m * pix_bytes + (unsigned)fh * 32u : 0xffffffffu;
 #pragma unroll
         for (int ks = 0; ks < KH; ++ks) {
+            // (nt loads here: 452.8 vs 457 img/s, measured -- the wgrad of the same layer re-reads x from the Infinity Cache)
             ra[ks][0] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 64u);
             ra[ks][1] = y4_buf_load4(src_rsrc, off, (unsigned)(ks0 + ks) * 64u + 16u);
         }

@@ -254,14 +254,12 @@ def planes_fit(B, H, W, ci, co, k, s, dgrad=True):
 
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
 _S2_DGRAD_PLANES = os.environ.get('Y4_PLANES_S2_DGRAD', '1') != '0'      # (A/B switch: 0 = register-staged stride-2 dgrad over an fp32 twin of dy)
-# bf16 conv RESULTS on the plane layers of conv mode 'bf16' (y4_conv2d_fwd_planes_f32 y_bf16): built, bit-exact against its
-# definition (tests/test_gpu_planes.py), and OFF by default -- the three BatchNorm sweeps that read y are bound by the bytes they
-# keep in flight, not by the bytes they move: with 8-B instead of 16-B loads per lane the step time did not change (599.0 vs
-# 600.5 img/s at bs = 128, A/B on one box), and twice the row groups in flight cost the sweeps their occupancy (550 img/s);
-# with a forward sweep of its own that keeps the loaded bf16 values packed (bn_act_fwd_bf16y_kernel: 8 row groups at the
-# register count of 4) it is worth 0.8 % (605.4 vs 600.6 img/s) -- most BatchNorm bytes of the step belong to the stage-1 / 2
-# maps, which are not plane layers.  Not worth a second rounding of every conv result by default.
-_BF16_Y = os.environ.get('Y4_BF16_Y', '0') == '1'
+# bf16 conv RESULTS on the plane layers of conv mode 'bf16' (y4_conv2d_fwd_planes_f32 y_bf16; what autocast does to a conv's
+# output): the three BatchNorm sweeps read y at half the width.  ON by default since round 4's rewrite of the sweeps: +2.8 %
+# (618.4 / 619.5 vs 602.6 / 601.6 img/s at bs = 128, A/B on one box).  With the old sweeps it measured +-0 -- their run-time
+# `ybf` branch made the backward sweeps wait for every bf16 load before issuing the next (pointwise.hip, "How the three
+# BatchNorm sweeps address memory"), not, as first concluded, a limit on bytes in flight.  Y4_BF16_Y=0: fp32 results.
+_BF16_Y = os.environ.get('Y4_BF16_Y', '1') != '0'
 
 
 def conv_fwd_raw(x, w, k, s, scale=None, shift=None, act='linear', residual=None, out=None, out_pad=1, x_amax=None,
