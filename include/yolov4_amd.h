@@ -252,11 +252,19 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
                                 float* mean, float* invstd, float* running_mean, float* running_var,
                                 long long* num_batches_tracked, float momentum, float eps,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* The analytic bound of max|act(BatchNorm(y))| that y4_bn_act_fwd_f32 (z_planes == 2) derives by itself, as a call of its own:
+ * *out = max(bound(gamma, beta, M), floor_word ? *floor_word : 0).  For SEVERAL BatchNorm layers that write channel slices of one
+ * pre-split tensor (the concat in front of a CSP transition conv, darknet/darknet.py:154-163 in the reference): chain the calls
+ * through floor_word, then hand the joint word to every producer's y4_bn_act_fwd_f32 with z_planes == 1, z = its slice and
+ * ldz = the pitch of the whole tensor -- one scale for the whole operand, no measuring pass. */
+int y4_bn_planes_bound_f32(const float* gamma, const float* beta, int C, long long M, const unsigned* floor_word, unsigned* out,
+                           void* stream);
 /* z = act(gamma*(y-mean)*invstd + beta) + residual   (residual may be NULL).
  * out_amax (nullable, device word): max|finite z| is folded into it with atomicMax (the caller zeroes it, or it
  * already holds the maximum of other parts of the same concat buffer) -- the operand maximum of conv mode 3.
  * z == NULL: measure only (max|z| into *out_amax, nothing stored).
- * z_planes != 0: z (ldz == C, C % 32 == 0) receives the tensor PRE-SPLIT for the plane conv kernels -- per pixel and
+ * z_planes != 0: z (C % 32 == 0; ldz == C, or z = a channel slice of a wider pre-split tensor: ldz % 32 == 0 and z 128-B aligned --
+ * for z_planes == 3 the slice of channels [c, c + C) starts at byte 2 c of the row) receives the tensor PRE-SPLIT for the plane conv kernels -- per pixel and
  * 32-channel K tile [64 B: hi halfs | 64 B: scaled lo halfs], 4 bytes per element -- scaled by the power of two that
  * *out_amax implies.  z_planes == 1: *out_amax must already hold max|z| or an upper bound (e.g. a measure-only call on the
  * same arguments).  z_planes == 2: the call derives the bound itself, without a pass over the data -- |xhat| <= sqrt(M - 1)

@@ -20,6 +20,9 @@ SHAPES = [  # ci, co, k, s, H
 ]
 
 
+# the stage-1 / stage-2 layers with 64 output channels (half-empty 128-column tiles): Y4_MICRO_SHAPES=small
+SMALL = [(64, 64, 1, 1, 304), (64, 64, 1, 1, 152), (128, 64, 1, 1, 152), (64, 64, 3, 1, 152), (128, 64, 1, 1, 304)]
+
 MODE = 'fwd'
 
 
@@ -30,7 +33,13 @@ def main():
     only = [int(i) for i in sys.argv[3].split(',')] if len(sys.argv) > 3 else None      # indices into SHAPES
     dev = torch.device('cuda:0')
     out = []
-    for ci, co, k, s, H in ([SHAPES[i] for i in only] if only else SHAPES):
+    shapes = SMALL if os.environ.get('Y4_MICRO_SHAPES') == 'small' else SHAPES
+    ybf = False
+    if os.environ.get('Y4_MICRO_BF16') == '1':       # plane arm: bf16 operands (and results); register-staged arm: f16x2 (the hybrid)
+        import yolov4_amd
+        yolov4_amd.set_conv_mode('bf16')
+        ybf = True
+    for ci, co, k, s, H in ([shapes[i] for i in only] if only else shapes):
         x = torch.randn(B, ci, H, H, device=dev).contiguous(memory_format=torch.channels_last)
         w = (torch.randn(co, ci, k, k, device=dev) / np.sqrt(ci * k * k)).contiguous(memory_format=torch.channels_last)
         xa = ops.amax_raw(x)
@@ -62,7 +71,7 @@ def main():
             print('max |agpr - product| / max:', float((ya - yb).abs().max() / ya.abs().max()), ops.last_conv_kernel(), flush=True)
         elif MODE == 'fwd':
             arms = {'regstage': lambda: ops.conv_fwd_bnstats_raw(x, w, k, s, None, None, None, 0.1, 1e-5, x_amax=xa),
-                    'planes': lambda: ops.conv_fwd_planes_raw(xp, w, k, s)}
+                    'planes': lambda: ops.conv_fwd_planes_raw(xp, w, k, s, y_bf16=ybf and co % 32 == 0)}
         else:
             if s != 1:
                 continue

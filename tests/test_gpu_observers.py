@@ -170,16 +170,67 @@ def test_csp_fork_fan_in_folded_into_the_dgrad_epilogue(dev, stage):
         (blk(x) * w).sum().backward()
         torch.cuda.synchronize()
         return x.grad.clone(), [p.grad.clone() for p in blk.parameters()]
-    was = D._FORK_FOLD
+    was, was_cat = D._FORK_FOLD, D._CAT_PLANES
     try:
+        D._CAT_PLANES = False                           # (a hook on part1 also switches the pre-split concat off: not this test's subject)
         gx1, gp1 = run(True)
         gx0, gp0 = run(False)
         h = blk.part1.register_forward_hook(lambda m, i, o: None)
         gxh, _ = run(True)                              # observed: no box, autograd's own fan-in
         h.remove()
     finally:
-        D._FORK_FOLD = was
+        D._FORK_FOLD, D._CAT_PLANES = was, was_cat
     assert float((gx1 - gx0).abs().max()) <= 2e-5 * float(gx0.abs().max())
     assert torch.equal(gxh, gx0)
     for a, b in zip(gp1, gp0):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16'])
+def test_csp_concat_written_pre_split_feeds_the_transition_conv_on_the_plane_kernels(dev, mode):
+    """darknet._CAT_PLANES: the two producers of the concat in front of a CSP transition conv (darknet.py:154-163 in the reference)
+    write their slots of the buffer pre-split under ONE joint scale (y4_bn_planes_bound_f32 chained), the concat-fed 1x1 conv
+    runs forward / dgrad / wgrad on the DMA kernels -- against the same block with the switch off (fp32 concat, gather kernels):
+    fp32-grade agreement in f16x2, bf16-grade in the bf16 mode; and a hook on the block switches it off."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd.darknet import darknet as D
+    torch.manual_seed(11)
+    blk = D.CSPDownSample(128, 256, 3, 2, num_blocks=2).to(dev).train()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+    S = 40
+    x = torch.randn(3, 128, S, S, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(3, 256, S // 2, S // 2, device=dev).contiguous(memory_format=torch.channels_last)
+    seen = []
+
+    def run(on):
+        D._CAT_PLANES = on
+        for p in blk.parameters():
+            p.grad = None
+        x.grad = None
+        out = blk(x)
+        seen.append(ops.last_conv_kernel())          # the block's last conv = the transition conv
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blk.parameters()]
+    was, old_mode = D._CAT_PLANES, yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode(mode)
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+        h = blk.register_forward_hook(lambda m, i, o: None)
+        oh, gxh, _ = run(True)                       # observed: the fp32 concat
+        h.remove()
+    finally:
+        D._CAT_PLANES = was
+        yolov4_amd.set_conv_mode(old_mode)
+    assert 'conv_planes_mfma' in seen[0] and 'conv_planes_mfma' not in seen[1] and 'conv_planes_mfma' not in seen[2], seen
+    tol_o, tol_g = (2e-5, 2e-4) if mode == 'f16x2' else (3e-2, 1.5e-1)
+    assert float((o1 - o0).abs().max()) <= tol_o * float(o0.abs().max())
+    assert float((gx1 - gx0).abs().max()) <= tol_g * float(gx0.abs().max())
+    for a, b in zip(gp1, gp0):
+        assert float((a - b).abs().max()) <= tol_g * max(float(b.abs().max()), 1e-6)
+    assert torch.equal(oh, o0) and torch.equal(gxh, gx0)

@@ -228,7 +228,7 @@ __device__ __forceinline__ void amax_commit(unsigned m, unsigned* out) {
 // maximum (conv_f16x2.hip, header) -- activations of interest sit within 2^-12 of it.  One block, C <= a few thousand.
 __global__ __launch_bounds__(256) void bn_planes_bound_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, int C,
                                                               float sqrt_m1, const unsigned* __restrict__ res_amax,
-                                                              unsigned* __restrict__ out) {
+                                                              unsigned* __restrict__ out, const unsigned* __restrict__ floor_word = nullptr) {
     __shared__ float red[256];
     float m = 0.f;
     for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, fabsf(gamma[c]) * sqrt_m1 + fabsf(beta[c]));
@@ -241,7 +241,11 @@ __global__ __launch_bounds__(256) void bn_planes_bound_kernel(const float* __res
     if (threadIdx.x == 0) {
         float b = red[0] * 1.0001f;
         if (res_amax) b += __uint_as_float(*res_amax) * 1.0001f;
-        *out = __float_as_uint(b);                         // a NaN / Inf parameter poisons the bound -> scale 1 (f16x2_scale_exp)
+        unsigned w = __float_as_uint(b);                   // a NaN / Inf parameter poisons the bound -> scale 1 (f16x2_scale_exp)
+        // floor_word: the bound of ANOTHER producer writing into the same pre-split tensor (a concat buffer): the larger bit
+        // pattern wins -- the larger value for finite bounds, and a poisoned (Inf / NaN) word stays poisoned
+        if (floor_word && *floor_word > w) w = *floor_word;
+        *out = w;
     }
 }
 
@@ -1012,6 +1016,16 @@ int y4_bn_finalize_partials_f32(const float* partials, long long nparts, long lo
     return Y4_OK;
 }
 
+int y4_bn_planes_bound_f32(const float* gamma, const float* beta, int C, long long M, const unsigned* floor_word, unsigned* out,
+                           void* stream) {
+    if (!gamma || !beta || !out) return Y4_ERR_NULL;
+    if (C <= 0 || M <= 0) return Y4_ERR_SHAPE;
+    hipLaunchKernelGGL(bn_planes_bound_kernel, dim3(1), dim3(256), 0, y4_stream(stream), gamma, beta, C,
+                       sqrtf((float)(M > 1 ? M - 1 : 1)), nullptr, out, floor_word);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+
 int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int act,
                       const float* residual, int ldr, float* z, int ldz,
@@ -1023,7 +1037,10 @@ int y4_bn_act_fwd_f32(const float* y, int ldy, const float* mean, const float* i
     if (!z && (!out_amax || z_planes)) return Y4_ERR_NULL;                       // measure-only needs the word to fill
     if (z_planes < 0 || z_planes > 3) return Y4_ERR_SHAPE;
     if (planes_twin && (!z_planes || (reinterpret_cast<uintptr_t>(planes_twin) & 15))) return Y4_ERR_SHAPE;
-    if (z_planes && ((!out_amax && z_planes != 3) || (!planes_twin && ldz != C) || (C & 31))) return Y4_ERR_SHAPE;   // planes: dense rows, whole K tiles
+    // planes: whole K tiles; rows dense, or a channel slice of a wider pre-split tensor (a concat buffer: pitch and slice offset
+    // in whole 32-channel tiles, i.e. z 128-B aligned)
+    if (z_planes && ((!out_amax && z_planes != 3) || (C & 31))) return Y4_ERR_SHAPE;
+    if (z_planes && !planes_twin && ldz != C && (ldz < C || (ldz & 31) || (reinterpret_cast<uintptr_t>(z) & 127))) return Y4_ERR_SHAPE;
     if (z_planes == 2) {
         // the scale comes from an analytic bound of max|z| (no measuring pass); a residual must bring its own maximum
         if (residual && !res_amax) return Y4_ERR_NULL;

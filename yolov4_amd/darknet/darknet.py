@@ -64,6 +64,7 @@ class ConvBNAct(nn.Module):
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
                'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes, 'dx_put': dx_put,
+               'out_cat': getattr(out, 'y4_cat', None),
                'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self, x.shape[2:], geo_of(x)) else None,
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:
@@ -190,6 +191,8 @@ _TWIN_RES = os.environ.get('Y4_TWIN_RES', '1') != '0'
 # The gradient fan-in of a CSP fork (the stride-2 conv's result feeds the two 1x1 split convs): the split conv whose backward
 # runs first parks its dx, the other adds it in its dgrad epilogue instead of a separate add pass (Y4_FORK_FOLD=0: off)
 _FORK_FOLD = os.environ.get('Y4_FORK_FOLD', '1') != '0'
+# The concat-fed CSP transition convs on the plane kernels (their producers write the concat buffer pre-split; Y4_CAT_PLANES=0: off)
+_CAT_PLANES = os.environ.get('Y4_CAT_PLANES', '1') != '0'
 
 
 def fork_box(x, *convs):
@@ -270,7 +273,14 @@ class CSPDownSample(nn.Module):
         both = soft(bool(_TWIN_RES and takes_planes(self.part1, geo=go) and takes_planes(self.part2[0], geo=go)),
                     self.part1, self.part2, self.part2[0])
         xa, xb = ops.fork(self.base(x, out_planes=both))
-        cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels])
+        # the concat in front of the transition conv: where that conv takes planes and nobody is looking, its two producers'
+        # BatchNorm sweeps write their slots of the buffer pre-split (one joint scale, ops.CatBuffer) and the concat-fed 1x1
+        # conv runs forward, dgrad and wgrad on the DMA kernels instead of the register-staged gather kernels
+        cat_planes = (_CAT_PLANES and takes_planes(self.transition, geo=go) and self.part1.has_bn and self.part2[2].has_bn
+                      and self.part1.training and self.part2[2].training
+                      and not observed(self, self.part1, self.part2, self.part2[2], self.transition))
+        cb = ops.cat_buffer(xa, [self.part2[2].conv.out_channels, self.part1.conv.out_channels],
+                            planes_norms=(self.part2[2].norm, self.part1.norm) if cat_planes else None)
         fb = None if observed(self.part2) else fork_box(xa, self.part1, self.part2[0])
         x1 = self.part1(xa, out=cb.slot(1), dres_take=fb)
         if observed(self.part2):

@@ -638,6 +638,21 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
     if residual is not None:
         residual, ldr = as_nhwc(residual)
     yb = 16 if y_bf16 else 0                         # y holds bf16 values (conv_fwd_planes_raw y_bf16)
+    if planes == 'slot':
+        # out: a slot of a pre-split CatBuffer (its cell already holds the joint bound of all producers: scale as given)
+        cb = out.y4_cat
+        if residual is not None or not _slot_ok(out, (B, C, H, W)):
+            raise Y4Error('a pre-split concat slot takes a BatchNorm result of its own shape, without a skip operand')
+        bf = planes_mode() == 'bf16'
+        zp = out.data_ptr()
+        if bf:
+            # bf16 rows keep their values in the FIRST HALF of the fp32-sized pixel row: channel c of the concat sits at byte 2 c of
+            # the row, not at the slot's fp32 address 4 c
+            zp = cb.buf.data_ptr() + (zp - cb.buf.data_ptr()) // 2
+        check(L.y4_bn_act_fwd_f32(_ptr(y), ldy, _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(beta), ACT_IDS[act], None, 0,
+                                  ctypes.c_void_p(zp), nhwc_pitch(out), B * H * W, C, None if bf else _ptr(cb.cell[0:1]),
+                                  (3 if bf else 1) + yb, None, None, _stream()), 'bn_act_fwd(planes slot)')
+        return out
     if planes:
         both = planes == 'both'
         zp = empty_nhwc(B, C, H, W, y.device)        # the pre-split tensor (float32-typed, 4 bytes per element)
@@ -857,7 +872,14 @@ class ConvBNActFn(torch.autograd.Function):
                                                        cfg['nbt'], cfg['momentum'], cfg['eps'], x_amax=x_amax,
                                                        dgrad_filter=ctx.dgrad_filter)
             want = cfg.get('out_planes')
-            if want and (f16 or bfm) and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
+            cb = cfg.get('out_cat')
+            if cb is not None and cb.planes:
+                # a slot of a pre-split concat buffer (CatBuffer planes_norms): the activation goes there as planes
+                z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest, planes='slot', y_bf16=ybf)
+                if io is not None:
+                    io['z_planes'] = True
+                z_amax = cb.cell[0:1] if cb.cell is not None else None
+            elif want and (f16 or bfm) and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
                 z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest if want == 'both' else None,
                                    planes='both' if want == 'both' else True, y_bf16=ybf)
                 z_amax = getattr(z, 'y4_amax', None)
@@ -1079,15 +1101,36 @@ class CatBuffer:
     occupy; a producer that accepts `out=` (ConvBNAct, Upsample) writes there directly and `cat(..., into=)` then
     has nothing to copy for it (inputs produced elsewhere are copied as usual)."""
 
-    def __init__(self, B, sizes, H, W, device):
+    def __init__(self, B, sizes, H, W, device, planes_norms=None):
         self.sizes = list(sizes)
         self.buf = empty_nhwc(B, sum(self.sizes), H, W, device)
         self.offsets = [sum(self.sizes[:i]) for i in range(len(self.sizes))]
         # conv mode 3: ONE operand-maximum cell for the whole buffer, every producer folds into it
         self.amax = new_amax(device) if (device.type == 'cuda' and f16x2_mode()) else None
+        # planes_norms (one training-mode BatchNorm2d per slot): the buffer is a PRE-SPLIT tensor -- every slot is written as
+        # planes by its producer's BatchNorm sweep (the slot's channel tiles of the [pixel][C/32][128 B] rows), the concat is
+        # consumed by a conv on the DMA kernels.  f16x2 planes share ONE scale: the joint analytic bound of all producers,
+        # formed here, before any of them runs (y4_bn_planes_bound_f32 chained through its floor word).
+        self.planes = False
+        pm = planes_mode()
+        q = 64 if pm == 'bf16' else 32
+        if planes_norms is not None and pm is not None and device.type == 'cuda' and all(c % q == 0 for c in self.sizes):
+            self.planes = True
+            self.cell = None
+            if pm == 'f16x2':
+                self.cell = planes_cell(device)
+                M = B * H * W
+                for i, n in enumerate(planes_norms):
+                    check(lib().y4_bn_planes_bound_f32(_ptr(n.weight), _ptr(n.bias), self.sizes[i], M,
+                                                       _ptr(self.cell[0:1]) if i else None, _ptr(self.cell[0:1]), _stream()),
+                          'bn_planes_bound')
+                self.amax = self.cell[0:1]
 
     def slot(self, i):
-        return tag_amax(self.buf[:, self.offsets[i]:self.offsets[i] + self.sizes[i]], self.amax)
+        t = tag_amax(self.buf[:, self.offsets[i]:self.offsets[i] + self.sizes[i]], self.amax)
+        if self.planes:
+            t.y4_cat = self                          # ConvBNActFn writes its activation here pre-split (cfg 'out_cat')
+        return t
 
 
 class CatFn(torch.autograd.Function):
@@ -1106,7 +1149,11 @@ class CatFn(torch.autograd.Function):
             _require_gpu(t, 'cat input')
             dst = out[:, o:o + t.shape[1]]
             if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride()):
+                if into is not None and into.planes:
+                    raise Y4Error('a pre-split concat buffer takes only inputs its producers wrote in place')
                 copy_into_raw(t, dst)
+            elif into is not None and into.planes != bool(getattr(t, 'y4_planes', False)):
+                raise Y4Error('concat buffer and input disagree on the pre-split form')
             o += t.shape[1]
         return out
 
@@ -1121,6 +1168,8 @@ class CatFn(torch.autograd.Function):
 
 def cat(xs, into=None):
     out = CatFn.apply(into, *xs)
+    if into is not None and into.planes and out.data_ptr() == into.buf.data_ptr():
+        return as_planes(out, into.cell[0:1] if into.cell is not None else None)
     if into is not None and into.amax is not None and out.data_ptr() == into.buf.data_ptr():
         for t in xs:                                 # inputs that were copied in bring their own maximum
             cell = amax_of(t)
@@ -1132,10 +1181,10 @@ def cat(xs, into=None):
     return out
 
 
-def cat_buffer(like, sizes, hw=None):
-    """CatBuffer for inputs shaped like `like` ([B, *, H, W]; hw overrides the spatial size)."""
+def cat_buffer(like, sizes, hw=None, planes_norms=None):
+    """CatBuffer for inputs shaped like `like` ([B, *, H, W]; hw overrides the spatial size).  planes_norms: see CatBuffer."""
     H, W = hw if hw is not None else (like.shape[2], like.shape[3])
-    return CatBuffer(like.shape[0], sizes, H, W, like.device)
+    return CatBuffer(like.shape[0], sizes, H, W, like.device, planes_norms=planes_norms)
 
 
 class SppPoolCatFn(torch.autograd.Function):
