@@ -234,3 +234,62 @@ def test_csp_concat_written_pre_split_feeds_the_transition_conv_on_the_plane_ker
     for a, b in zip(gp1, gp0):
         assert float((a - b).abs().max()) <= tol_g * max(float(b.abs().max()), 1e-6)
     assert torch.equal(oh, o0) and torch.equal(gxh, gx0)
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16'])
+def test_fpn_concats_written_pre_split_through_the_upsample(dev, mode):
+    """FPNBlock (yolov4.py:93-141 in the reference): cat([lateral(x), upsample(reduce(f))]) -- the lateral conv writes its slot
+    of the concat buffer pre-split, the reducing conv writes planes under the buffer's joint scale (its bound over the SMALL
+    map's pixel count) and the x2 upsample copies those pixel rows into the other slot; against the switch off."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd.darknet import darknet as D
+    from yolov4_amd.yolo.model.yolov4 import FPNBlock
+    torch.manual_seed(13)
+    blk = FPNBlock().to(dev).train()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+        if isinstance(m, D.ConvBNAct):
+            # the block's LeakyReLU has a kink: a pre-activation within rounding of zero takes the other slope in the other arm,
+            # and BatchNorm backward spreads that over its whole channel -- Mish here, so that the arms can be compared tightly
+            m.act_name = 'mish'
+    h = 9
+    xs = [torch.randn(2, c, h * f, h * f, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for c, f in ((256, 4), (512, 2), (512, 1))]
+    ws = [torch.randn(2, c, h * f, h * f, device=dev).contiguous(memory_format=torch.channels_last) for c, f in ((128, 4), (256, 2), (512, 1))]
+
+    def run(on):
+        D._CAT_PLANES = on
+        for p in blk.parameters():
+            p.grad = None
+        for x in xs:
+            x.grad = None
+        outs = blk(*xs)
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], [p.grad.clone() for p in blk.parameters()]
+    was, old_mode = D._CAT_PLANES, yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode(mode)
+        assert blk._cat_planes(blk.conv4, blk.conv3, blk.upsample1, blk.module2, xs[1], xs[2]) is not None
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+        hk = blk.upsample1.register_forward_hook(lambda m, i, o: None)
+        assert blk._cat_planes(blk.conv4, blk.conv3, blk.upsample1, blk.module2, xs[1], xs[2]) is None
+        hk.remove()
+    finally:
+        D._CAT_PLANES = was
+        yolov4_amd.set_conv_mode(old_mode)
+    if mode == 'f16x2':                              # fp32-grade either way
+        for a, b in zip(o1, o0):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+        for a, b in zip(gx1 + gp1, gx0 + gp0):
+            assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-6)
+    else:
+        # hybrid bf16 mode: with the switch on, the two concat-fed convs compute in bf16 instead of fp32-grade -- a bf16-grade
+        # difference (mean error against the tensor's range; BatchNorm backward over a few hundred samples amplifies single
+        # roundings, so no max-norm statement)
+        for a, b in zip(o1 + gx1 + gp1, o0 + gx0 + gp0):
+            assert float((a - b).abs().mean()) <= 2e-2 * max(float(b.abs().max()), 1e-6)

@@ -51,20 +51,21 @@ class ConvBNAct(nn.Module):
         self.stride = stride
         self.has_bn = bool(bn)
 
-    def forward(self, x, residual=None, out=None, dres_put=None, dres_take=None, out_planes=False, dx_put=None):
+    def forward(self, x, residual=None, out=None, dres_put=None, dres_take=None, out_planes=False, dx_put=None, scale_from=None):
         """out: optional destination (a CatBuffer slot) for the activation; dres_put / dres_take: the shared box through
         which a ResBlock unit's 3x3 conv hands the skip gradient to its 1x1 conv (see ResBlock); out_planes: the caller
         guarantees that the SOLE consumer of the result is a ConvBNAct for which `takes_planes()` holds, so the
         activation may leave pre-split for the DMA-fed conv kernels (csrc/conv_planes.hip) instead of as fp32;
         out_planes='both': such a consumer exists beside fp32 ones -- the result is fp32 and carries a pre-split twin
-        (tensor attribute y4_twin, handed on by ops.fork).  The reference has none of these arguments."""
+        (tensor attribute y4_twin, handed on by ops.fork); scale_from: a pre-split ops.CatBuffer whose joint scale a planes-only
+        result is written under (it will be copied into that buffer by an Upsample).  The reference has none of these arguments."""
         n = self.norm
         io = {}
         out_planes = soft(out_planes, self)
         cfg = {'out': out, 'k': self.kernel_size, 's': self.stride, 'act': self.act_name, 'bn': self.has_bn,
                'training': self.training, 'io': io, 'x_amax': ops.amax_of(x), 'out_amax': ops.amax_of(out),
                'dres_put': dres_put, 'dres_take': dres_take, 'out_planes': out_planes, 'dx_put': dx_put,
-               'out_cat': getattr(out, 'y4_cat', None),
+               'out_cat': getattr(out, 'y4_cat', None), 'scale_from': scale_from,
                'x_twin': getattr(x, 'y4_twin', None) if takes_planes(self, x.shape[2:], geo_of(x)) else None,
                'grad': torch.is_grad_enabled()}      # (autograd.Function.forward itself always runs with grad mode off)
         if self.has_bn:

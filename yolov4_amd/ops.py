@@ -627,7 +627,7 @@ def _slot_ok(out, shape):
             and out.data_ptr() % 16 == 0)
 
 
-def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None, planes=False, y_bf16=False):
+def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, out_amax=None, planes=False, y_bf16=False, cell=None):
     """planes: z leaves PRE-SPLIT for the plane conv kernels (a float32-typed tensor whose 4 bytes per element hold the two
     fp16 pieces; tagged y4_planes), scaled by an analytic bound of max|z| that the call leaves in the tensor's cell (no
     measuring pass; with a residual whose maximum is unknown: one measure-only launch first)."""
@@ -666,9 +666,14 @@ def bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual=None, out=None, o
                 z.y4_twin = zp
                 return z
             return zp
-        cell = planes_cell(y.device)
+        given = cell is not None                     # cell: the scale is ALREADY fixed (the joint bound of a pre-split concat buffer)
+        if given and (residual is not None or both):
+            raise Y4Error('a given plane scale goes with a plain planes-only result')
+        cell = cell if given else planes_cell(y.device)
         res_cell = amax_of(residual) if residual is not None else None
-        if residual is not None and res_cell is None:
+        if given:
+            mode = 1
+        elif residual is not None and res_cell is None:
             check(L.y4_bn_act_fwd_f32(*args, None, C, B * H * W, C, _ptr(cell), yb, None, None, _stream()), 'bn_act_fwd(measure)')
             mode = 1
         else:
@@ -880,8 +885,10 @@ class ConvBNActFn(torch.autograd.Function):
                     io['z_planes'] = True
                 z_amax = cb.cell[0:1] if cb.cell is not None else None
             elif want and (f16 or bfm) and y.shape[1] % 32 == 0 and (want == 'both' or dest is None):
+                sf = cfg.get('scale_from')               # a pre-split CatBuffer this result will be copied into (Upsample)
                 z = bn_act_fwd_raw(y, mean, invstd, gamma, beta, act, residual, out=dest if want == 'both' else None,
-                                   planes='both' if want == 'both' else True, y_bf16=ybf)
+                                   planes='both' if want == 'both' else True, y_bf16=ybf,
+                                   cell=sf.cell if (sf is not None and sf.planes and sf.cell is not None and want is True) else None)
                 z_amax = getattr(z, 'y4_amax', None)
                 if io is not None:
                     io['z_planes'] = want != 'both'
@@ -1119,8 +1126,9 @@ class CatBuffer:
             self.cell = None
             if pm == 'f16x2':
                 self.cell = planes_cell(device)
-                M = B * H * W
                 for i, n in enumerate(planes_norms):
+                    # (norm, M): a producer whose BatchNorm ran over M pixels of its own (the layer in front of an Upsample)
+                    n, M = n if isinstance(n, tuple) else (n, B * H * W)
                     check(lib().y4_bn_planes_bound_f32(_ptr(n.weight), _ptr(n.bias), self.sizes[i], M,
                                                        _ptr(self.cell[0:1]) if i else None, _ptr(self.cell[0:1]), _stream()),
                           'bn_planes_bound')
@@ -1266,7 +1274,21 @@ class Upsample2xFn(torch.autograd.Function):
         L = lib()
         _require_gpu(x, 'upsample input')
         B, C, H, W = x.shape
+        xpl = bool(getattr(x, 'y4_planes', False))
+        cb = getattr(out.t, 'y4_cat', None) if out is not None else None
         x, ldx = as_nhwc(x)
+        if xpl or (cb is not None and cb.planes):
+            # a pre-split tensor into its slot of a pre-split concat buffer: pixel rows are copied as they are (f16x2: the
+            # source was written under the buffer's joint scale; bf16: the C values sit in the first 2 C bytes of the row and
+            # go to byte 2 * (channel offset) of the concat's row)
+            if not (xpl and cb is not None and cb.planes and _slot_ok(out.t, (B, C, 2 * H, 2 * W))):
+                raise Y4Error('upsample: a pre-split tensor goes into a pre-split concat slot of its shape, and nothing else does')
+            dst, cols = out.t.data_ptr(), C
+            if planes_mode() == 'bf16':
+                dst, cols = cb.buf.data_ptr() + (dst - cb.buf.data_ptr()) // 2, C // 2
+            check(L.y4_upsample2x_fwd_f32(_ptr(x), ldx, ctypes.c_void_p(dst), nhwc_pitch(out.t), B, H, W, cols, _stream()), 'upsample(planes)')
+            ctx.shape = (B, C, H, W)
+            return out.t
         out = out.t if (out is not None and _slot_ok(out.t, (B, C, 2 * H, 2 * W))) else empty_nhwc(B, C, 2 * H, 2 * W, x.device)
         check(L.y4_upsample2x_fwd_f32(_ptr(x), ldx, _ptr(out), nhwc_pitch(out), B, H, W, C, _stream()), 'upsample')
         ctx.shape = (B, C, H, W)

@@ -74,6 +74,8 @@ class Upsample(nn.Module):
         slot = ops.Slot(out) if out is not None else None
         Ht, Wt = int(target_size[2]), int(target_size[3])
         if Ht == 2 * x.shape[2] and Wt == 2 * x.shape[3]:
+            if getattr(x, 'y4_planes', False):       # pre-split, into its slot of a pre-split concat buffer (FPNBlock)
+                return ops.as_planes(ops.Upsample2xFn.apply(x, slot), getattr(x, 'y4_amax', None))
             return self._tag(ops.Upsample2xFn.apply(x, slot), x, out)      # the YOLOv4 neck at S % 32 == 0
         # any other target (e.g. S = 600: 19 -> 38 -> 75): train = F.interpolate(size=target, nearest) (yolov4.py:85);
         # eval = integer-factor expand whose final view() needs target % input == 0 (yolov4.py:87-90)
@@ -112,18 +114,32 @@ class FPNBlock(nn.Module):
         """head_planes: head.yolo1[0] (one of the two consumers of f1) takes a pre-split input."""
         f3 = chain(self.module1, x5)
         f3a, f3b = ops.fork(f3)
-        cb = ops.cat_buffer(x4, [256, 256])                      # [conv4(x4) | upsampled conv3(f3)], written in place
-        up = self.upsample1(self.conv3(f3a), x4.size(), out=cb.slot(1))
+        pn = self._cat_planes(self.conv4, self.conv3, self.upsample1, self.module2, x4, f3a)
+        cb = ops.cat_buffer(x4, [256, 256], planes_norms=pn)     # [conv4(x4) | upsampled conv3(f3)], written in place
+        up = self.upsample1(self.conv3(f3a, out_planes=bool(pn), scale_from=cb if pn else None), x4.size(), out=cb.slot(1))
         x4 = self.conv4(x4, out=cb.slot(0))
         assert up.shape[2:] == x4.shape[2:]
         f2 = chain(self.module2, ops.cat([x4, up], into=cb))
         f2a, f2b = ops.fork(f2)
-        cb = ops.cat_buffer(x3, [128, 128])
-        up = self.upsample2(self.conv10(f2a), x3.size(), out=cb.slot(1))
+        pn = self._cat_planes(self.conv11, self.conv10, self.upsample2, self.module3, x3, f2a)
+        cb = ops.cat_buffer(x3, [128, 128], planes_norms=pn)
+        up = self.upsample2(self.conv10(f2a, out_planes=bool(pn), scale_from=cb if pn else None), x3.size(), out=cb.slot(1))
         x3 = self.conv11(x3, out=cb.slot(0))
         assert up.shape[2:] == x3.shape[2:]
         f1 = chain(self.module3, ops.cat([x3, up], into=cb), last='both' if head_planes else False)
         return f1, f2b, f3b
+
+    def _cat_planes(self, lateral, reduce, up, five, x, f):
+        """planes_norms for the concat [lateral(x) | up(reduce(f))] in front of the block `five`, or None: where its first conv
+        takes planes, the upsample is the exact x2 one and nobody is looking, both producers write the concat buffer pre-split
+        under one joint scale (the reducing conv's BatchNorm ran over the SMALL map: its bound uses that pixel count) and the
+        concat-fed 1x1 conv runs on the DMA kernels (darknet._CAT_PLANES, ops.CatBuffer)."""
+        from ...darknet import darknet as D
+        if not (D._CAT_PLANES and x.shape[2] == 2 * f.shape[2] and x.shape[3] == 2 * f.shape[3]
+                and takes_planes(five[0], geo=geo_of(x)) and lateral.training and reduce.training
+                and not observed(self, lateral, reduce, up, five, five[0])):
+            return None
+        return (lateral.norm, (reduce.norm, int(f.shape[0]) * int(f.shape[2]) * int(f.shape[3])))
 
 
 class PANBlock(nn.Module):
