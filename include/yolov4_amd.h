@@ -162,6 +162,8 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
                              int y_bf16 /* != 0 (Cout % 32 == 0): y leaves as plain bf16 (RN) in the FIRST HALF of each fp32-sized row
                                 (pitch 4 ldy bytes), the column sums are those of the rounded values; the BatchNorm sweeps read it
                                 with y4_bn_act_fwd_f32 z_planes + 16 / y4_bn_act_bwd_f32 frozen_stats bit 2 */,
+                             const float* bias /* nullable [Cout]: added to every result row (a conv WITHOUT BatchNorm -- the head's
+                                output convs, yolo/model/yolov4.py:235-239 -- reading a pre-split input; partials NULL, y_bf16 0) */,
                              void* stream);
 
 /* dgrad / wgrad (stride 1, and the 3x3 stride-2 layers on even maps) of a conv over planes (dy, and for wgrad also
@@ -169,7 +171,9 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
  * conv mode 3 (conv mode 2: plain bf16 operands, 64-channel multiples, stride 1).  dgrad runs the forward DMA kernel on the
  * mirrored transposed filter (workspace: y4_conv2d_dgrad_workspace()); wgrad stages both operands pixel-major and takes its
  * fragments through the hardware transpose read (split-K slabs in y4_conv2d_wgrad_planes_workspace() bytes, fixed-order
- * reduce: deterministic); H, W are the INPUT dims.  Autograd of the same nn.Conv2d, darknet/darknet.py:31-36. */
+ * reduce: deterministic); H, W are the INPUT dims.  wgrad alone also takes a Cout that is NOT whole K tiles (the head's 255): dy's
+ * pixel rows then hold ceil(Cout / 32) tiles (64-channel units in the bf16 mode) whose pad channels are zero, dW has Cout rows.
+ * Autograd of the same nn.Conv2d, darknet/darknet.py:31-36. */
 int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w /* NULL: workspace prepared by the forward call */, float* dx, int lddx,
                                int B, int H, int W, int Cin, int Cout, int k,
                                int stride /* 1; or 2 (3x3, H and W even, conv mode 3 operands, no residual): four launches, one per

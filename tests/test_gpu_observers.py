@@ -293,3 +293,55 @@ def test_fpn_concats_written_pre_split_through_the_upsample(dev, mode):
         # roundings, so no max-norm statement)
         for a, b in zip(o1 + gx1 + gp1, o0 + gx0 + gp0):
             assert float((a - b).abs().mean()) <= 2e-2 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize('mode,k', [('f16x2', 3), ('f16x2', 1), ('bf16', 3)])
+def test_head_output_conv_without_batchnorm_over_a_pre_split_input(dev, mode, k):
+    """Head.yolo*[0:2] (yolov4.py:235-251 in the reference): ConvBNAct -> conv with bias, no BatchNorm, 255 output channels.
+    With darknet._HEAD_PLANES the 3x3 conv's activation leaves pre-split and the output conv runs forward (bias in the
+    skip-operand epilogue), dgrad and wgrad on the plane kernels, its 255 output channels padded with a zero filter to 256
+    and its gradient split by one extra pass -- against the switch off (fp32 activation, halo / gather kernels)."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd.darknet import darknet as D
+    torch.manual_seed(17)
+    a = D.ConvBNAct(128, 256, 3, 1, act='leaky_relu').to(dev).train()
+    b = D.ConvBNAct(256, 255, k, 1, bias=True, bn=False, act='linear').to(dev).train()
+    nn.init.uniform_(a.norm.weight, 0.8, 1.2)
+    nn.init.normal_(a.norm.bias, 0, 0.1)
+    nn.init.normal_(b.conv.bias, 0, 0.5)
+    x = torch.randn(3, 128, 21, 21, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(3, 255, 21, 21, device=dev).contiguous(memory_format=torch.channels_last)
+    kinds = []
+
+    def run(on):
+        D._HEAD_PLANES = on
+        for p in list(a.parameters()) + list(b.parameters()):
+            p.grad = None
+        x.grad = None
+        want = D.takes_planes(b, geo=(3, 21, 21))
+        z = a(x, out_planes=bool(want))
+        kinds.append(type(z).__name__)
+        out = b(z)
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]
+    was, old_mode = D._HEAD_PLANES, yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode(mode)
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+    finally:
+        D._HEAD_PLANES = was
+        yolov4_amd.set_conv_mode(old_mode)
+    assert kinds == ['PlanesTensor', 'Tensor']
+    assert o1.shape == o0.shape == (3, 255, 21, 21)
+    if mode == 'f16x2':
+        assert float((o1 - o0).abs().max()) <= 2e-5 * float(o0.abs().max())
+        for p1, p0 in zip([gx1] + gp1, [gx0] + gp0):
+            assert p1.shape == p0.shape
+            assert float((p1 - p0).abs().max()) <= 2e-4 * max(float(p0.abs().max()), 1e-6)
+    else:
+        for p1, p0 in zip([o1, gx1] + gp1, [o0, gx0] + gp0):
+            assert p1.shape == p0.shape
+            assert float((p1 - p0).abs().mean()) <= 2e-2 * max(float(p0.abs().max()), 1e-6)

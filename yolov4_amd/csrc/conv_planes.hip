@@ -323,7 +323,8 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
         const unsigned drow = (unsigned)g.ldd * 4u, rrow = (unsigned)g.ldr * 4u;
         const long long row0 = (long long)mt * BM;
         const unsigned long long left = (unsigned long long)(g.M - row0);
-        const unsigned long long dby = left * drow, rby = left * rrow;
+        // (ldr == 0: ONE row of N values added to every result row -- the bias of a conv without BatchNorm)
+        const unsigned long long dby = left * drow, rby = g.ldr ? left * rrow : (unsigned long long)g.N * 4ull;
         const __amdgpu_buffer_rsrc_t drs = y4_make_rsrc(reinterpret_cast<char*>(g.dst) + row0 * (long long)drow, (unsigned)(dby < 0xfffffff0ull ? dby : 0xfffffff0ull));
         const __amdgpu_buffer_rsrc_t rrs = y4_make_rsrc(g.res ? reinterpret_cast<const char*>(g.res) + row0 * (long long)rrow : nullptr,
                                                         g.res ? (unsigned)(rby < 0xfffffff0ull ? rby : 0xfffffff0ull) : 0u);
@@ -492,6 +493,7 @@ struct PlaneWgradGeom {
     const unsigned char* dy;           // planes [B][H][W][Cout / 32][128 B]
     float* out;                        // [splits][Cout][J] slabs, or dW itself when splits == 1
     int B, H, W, Cin, Cout, k, pad, M, J;   // H, W, M: the dy grid (= the x grid at stride 1; at stride 2 x is 2H x 2W)
+    int ldy_ch;                        // channels per dy pixel row: Cout rounded up to whole K tiles (pad channels hold zeros)
     int ntn, ntj, splits, steps_per_split;
     unsigned long long x_total_bytes, dy_total_bytes;
     const unsigned* x_amax; const unsigned* dy_amax;
@@ -556,7 +558,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
     const long long P0 = (long long)s0 * 32;               // first pixel of this split
 
     // ---- 32-bit windows: dy from pixel P0; x from pixel P0 - (pad W + pad) (the earliest pixel a tap can reach), >= 0
-    const unsigned pitch_x = (unsigned)g.Cin * 4u, pitch_dy = (unsigned)g.Cout * 4u;
+    const unsigned pitch_x = (unsigned)g.Cin * 4u, pitch_dy = (unsigned)g.ldy_ch * 4u;
     const long long back = SD == 1 ? (long long)g.pad * g.W + g.pad : 2ll * g.W + 2ll * g.W + 1;     // S = 2: 2 w <= 2 W, one x row (2 W) + 1
     const long long Pw = SD * SD * P0 > back ? SD * SD * P0 - back : 0;     // first x pixel of the window (x raster)
     const unsigned long long dy_skip = (unsigned long long)P0 * pitch_dy, x_skip = (unsigned long long)Pw * pitch_x;
@@ -1068,13 +1070,15 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     } else if (stride != 1) return Y4_ERR_SHAPE;
     g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.k = k; g.pad = (k - 1) / 2;
     const long long M = (long long)B * H * W;
-    if (bf && ((Cin & 63) || (Cout & 63))) return Y4_ERR_SHAPE;
-    if (!wgrad_window_ok(B, H, W, Cin, Cout, k, stride, bf)) return Y4_ERR_SHAPE;
+    const int q = bf ? 64 : 32;
+    g.ldy_ch = (Cout + q - 1) / q * q;                     // dy rows hold whole K tiles; channels >= Cout are zero (caller)
+    if (bf && (Cin & 63)) return Y4_ERR_SHAPE;
+    if (!wgrad_window_ok(B, H, W, Cin, g.ldy_ch, k, stride, bf)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.J = k * k * Cin;
     const int tn = planes_wgrad_tn(Cout, bf);
     planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split, tn);
     g.x_total_bytes = (unsigned long long)M * stride * stride * Cin * 4ull;
-    g.dy_total_bytes = (unsigned long long)M * Cout * 4ull;
+    g.dy_total_bytes = (unsigned long long)M * g.ldy_ch * 4ull;
     g.x_amax = x_amax; g.dy_amax = dy_amax;
     const size_t slab = (size_t)Cout * g.J * sizeof(float);
     if (g.splits > 1) {
@@ -1139,8 +1143,9 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
                              int B, int H, int W, int Cin, int Cout, int k, int stride,
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,
                              void* workspace, size_t workspace_bytes, void* dgrad_filter, size_t dgrad_filter_bytes,
-                             int y_bf16, void* stream) {
+                             int y_bf16, const float* bias, void* stream) {
     if (!x_planes || !w || !y || !workspace) return Y4_ERR_NULL;
+    if (bias && (y_bf16 || partials || (reinterpret_cast<uintptr_t>(bias) & 3))) return Y4_ERR_SHAPE;   // (a conv without BatchNorm: no statistics)
     if (!pl_mode_ok()) return Y4_ERR_SHAPE;
     const bool bf = pl_bf();
     if (!bf && !x_amax) return Y4_ERR_NULL;
@@ -1175,7 +1180,7 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
     }
     if (rc != Y4_OK) return rc;
     int np = 0;
-    rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, nullptr, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st, bf, y_bf16 != 0);
+    rc = y4::planes_conv(x_planes, x_amax, planes, hdr, y, ldy, bias, 0, partials, &np, B, H, W, Cin, Cout, k, stride, st, bf, y_bf16 != 0);
     if (nparts_host) *nparts_host = np;
     return rc;
 }
@@ -1245,7 +1250,9 @@ int y4_conv2d_wgrad_planes_f32(const void* x_planes, const void* dy_planes, floa
     if (!pl_mode_ok()) return Y4_ERR_SHAPE;
     const bool bf = pl_bf();
     if (!bf && (!x_amax || !dy_amax)) return Y4_ERR_NULL;
-    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 31) || Cout <= 0 || (Cout & 31) || (k != 1 && k != 3)) return Y4_ERR_SHAPE;
+    // (Cout need not be whole K tiles: dy's pixel rows then hold ceil(Cout / 32) tiles -- 64-channel units in the bf16 mode -- whose
+    //  pad channels are zero; dW has Cout rows)
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin & 31) || Cout <= 0 || (k != 1 && k != 3)) return Y4_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(x_planes) & 15) || (reinterpret_cast<uintptr_t>(dy_planes) & 15) ||
         (reinterpret_cast<uintptr_t>(dw) & 15) || (reinterpret_cast<uintptr_t>(workspace) & 15)) return Y4_ERR_SHAPE;
     if (workspace_bytes < y4_conv2d_wgrad_planes_workspace(B, H, W, Cin, Cout, k, stride)) return Y4_ERR_WORKSPACE;

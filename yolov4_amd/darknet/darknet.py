@@ -124,6 +124,8 @@ def takes_planes(m, hw=None, geo=None):
     of its input (forward and wgrad on the DMA kernels, dgrad on the register-staged parity-class kernel).
     geo = (B, H, W) of its input, where the caller knows it: the operands must also fit the kernels' 32-bit buffer windows
     (ops.planes_fit) -- a producer must never emit planes its consumer cannot address, there is no fp32 form to fall back to."""
+    if isinstance(m, ConvBNAct) and not m.has_bn:
+        return _nobn_takes_planes(m, geo)
     if not isinstance(m, ConvBNAct) or not m.has_bn or not m.training:
         return False
     if geo is not None and hw is None and m.stride == 1:
@@ -140,6 +142,28 @@ def takes_planes(m, hw=None, geo=None):
         return False
     # stride 2: backward picks the register-staged dgrad by itself when the plane one does not fit (ConvBNActFn.backward)
     return geo is None or ops.planes_fit(geo[0], geo[1], geo[2], ci, co, m.kernel_size, m.stride, dgrad=m.stride == 1)
+
+
+# The head's output convs (no BatchNorm, bias, linear; yolo/model/yolov4.py:235-251 in the reference) over a pre-split input
+# (Y4_HEAD_PLANES=0: off)
+_HEAD_PLANES = os.environ.get('Y4_HEAD_PLANES', '1') != '0'
+
+
+def _nobn_takes_planes(m, geo):
+    """A training-mode conv WITHOUT BatchNorm (bias, linear, stride 1) can take a pre-split input when autograd is on: its
+    output channels are padded to whole K tiles inside ConvBNActFn (255 -> 256), its gradient is split by one extra pass."""
+    if not (_HEAD_PLANES and m.training and torch.is_grad_enabled() and m.act_name == 'linear' and m.stride == 1
+            and m.kernel_size in (1, 3) and ops.PLANES['on'] and m.conv.weight.is_cuda):
+        return False
+    pm = ops.planes_mode()
+    if pm is None:
+        return False
+    q = 64 if pm == 'bf16' else 32
+    ci, co = m.conv.in_channels, m.conv.out_channels
+    cop = (co + q - 1) // q * q
+    if ci % q or ci < 64 or cop < 128:
+        return False
+    return geo is None or ops.planes_fit(geo[0], geo[1], geo[2], ci, cop, m.kernel_size, 1, dgrad=True)
 
 
 def geo_of(x, after=None):

@@ -428,14 +428,15 @@ def planes_split_raw(x, amax=None):
     return Planes(buf, (B, C, H, W), amax)
 
 
-def conv_fwd_planes_raw(xp, w, k, s, stats=True, dgrad_filter=None, y_bf16=False):
+def conv_fwd_planes_raw(xp, w, k, s, stats=True, dgrad_filter=None, y_bf16=False, bias=None, out=None):
     """Training-mode conv over a Planes input: raw output y (+ per-M-tile column sums, n_tiles).  y_bf16: y leaves as plain
-    bf16 in the first half of each row of the (float32-typed) result -- an internal tensor only the BatchNorm sweeps read."""
+    bf16 in the first half of each row of the (float32-typed) result -- an internal tensor only the BatchNorm sweeps read.
+    bias (with stats=False): added to every result row (a conv without BatchNorm); out: destination of y's shape."""
     L = lib()
     B, Cin, H, W = xp.shape
     Cout = w.shape[0]
     Ho, Wo = conv_out_hw(H, W, k, s)
-    y = empty_nhwc(B, Cout, Ho, Wo, xp.buf.device)
+    y = out if _slot_ok(out, (B, Cout, Ho, Wo)) else empty_nhwc(B, Cout, Ho, Wo, xp.buf.device)
     w = krsc(w)
     nbytes = L.y4_conv2d_fwd_workspace(Cin, Cout, k)
     ws = _ws(nbytes, xp.buf.device)
@@ -445,7 +446,7 @@ def conv_fwd_planes_raw(xp, w, k, s, stats=True, dgrad_filter=None, y_bf16=False
     check(L.y4_conv2d_fwd_planes_f32(_ptr(xp.buf), _ptr(w), _ptr(y), nhwc_pitch(y), B, H, W, Cin, Cout, k, s,
                                      _ptr(part), pbytes, ctypes.byref(n), _ptr(xp.amax), _ptr(ws), nbytes,
                                      _ptr(dgrad_filter), dgrad_filter.numel() if dgrad_filter is not None else 0,
-                                     1 if y_bf16 else 0, _stream()),
+                                     1 if y_bf16 else 0, _ptr(bias), _stream()),
           'conv2d_fwd_planes')
     return (y, part, n.value) if stats else y
 
@@ -819,6 +820,35 @@ def _wgrad_to_param(x, dy, param, k, s, x_amax=None, dy_amax=None, fn=None):
         torch.autograd.Variable._execution_engine.queue_callback(join_side_stream)
 
 
+def _pad_out_channels(weight, bias, cop):
+    """Filter [Cout, Cin, k, k] (+ bias) with zero rows up to cop output channels (whole K tiles for the plane dgrad / wgrad)."""
+    co = weight.shape[0]
+    if cop == co:
+        return weight, bias
+    wp = torch.zeros((cop,) + tuple(weight.shape[1:]), dtype=weight.dtype, device=weight.device).contiguous(memory_format=torch.channels_last)
+    wp[:co].copy_(weight)
+    bp = None
+    if bias is not None:
+        bp = torch.zeros(cop, dtype=bias.dtype, device=bias.device)
+        bp[:co].copy_(bias)
+    return wp, bp
+
+
+def _pad_channels_zero(t, cop):
+    """NHWC tensor [B, C, H, W] as [B, cop, H, W] with ZERO pad channels: the same memory when its pixel pitch already is cop
+    (the head gradients leave yolo_decode_bwd that way), else a copy."""
+    B, C, H, W = t.shape
+    t, ld = as_nhwc(t)
+    if ld == cop:
+        v = torch.as_strided(t, (B, cop, H, W), (H * W * cop, 1, W * cop, cop), t.storage_offset())
+    else:
+        v = empty_nhwc(B, cop, H, W, t.device)
+        v[:, :C].copy_(t)
+    if cop > C:
+        v[:, C:].zero_()
+    return v
+
+
 # ------------------------------------------------------------------ autograd functions
 class ConvBNActFn(torch.autograd.Function):
     """conv -> BatchNorm -> activation (+ skip), darknet/darknet.py:53-58 (+ :76-80)."""
@@ -846,8 +876,9 @@ class ConvBNActFn(torch.autograd.Function):
         if xp is None and cfg.get('x_twin') is not None:
             xp = planes_of(cfg['x_twin'])            # x itself is fp32 (it has other consumers); its pre-split twin feeds this conv
         ctx.x_planes = xp is not None
-        if xp is not None and not ((f16 or bfm) and bn and training and weight.shape[0] % 32 == 0 and x.shape[1] % 32 == 0
-                                   and (s == 1 or planes_stride2_ok(k, s, x.shape[2], x.shape[3]))):
+        nobn_planes = xp is not None and not bn and act == 'linear' and residual is None and s == 1 and cfg.get('grad', True)
+        if xp is not None and not ((f16 or bfm) and x.shape[1] % 32 == 0 and (nobn_planes or (
+                bn and training and weight.shape[0] % 32 == 0 and (s == 1 or planes_stride2_ok(k, s, x.shape[2], x.shape[3]))))):
             raise Y4Error('a pre-split (planes) tensor reached a conv that cannot consume it')
         x_amax = live(cfg.get('x_amax')) if f16 else None
         z_amax = None
@@ -934,6 +965,21 @@ class ConvBNActFn(torch.autograd.Function):
             z = conv_fwd_raw(x, weight, k, s, scale, shift, act, residual, out=o, x_amax=x_amax, out_amax=z_amax,
                              w_prepared=wprep)
             ctx.mode = 'bn_eval'
+        elif nobn_planes:
+            # a conv WITHOUT BatchNorm over a pre-split input (the head's output convs): its Cout (255) is padded with zero
+            # filters to whole K tiles, so that forward, dgrad and wgrad are plain plane-kernel calls; the bias rides the
+            # forward kernel's skip-operand epilogue (one row for every pixel)
+            co = weight.shape[0]
+            q = 64 if bfm else 32
+            cop = (co + q - 1) // q * q
+            wpad, bpad = _pad_out_channels(weight, bias, cop)
+            Ho, Wo = conv_out_hw(x.shape[2], x.shape[3], k, s)
+            zf = empty_nhwc(x.shape[0], cop, Ho, Wo, x.device)
+            ctx.dgrad_filter = dgrad_filter_buffer(x.shape[1], cop, k, x.device) if ctx.needs_input_grad[0] else None
+            conv_fwd_planes_raw(xp, wpad, k, s, stats=False, dgrad_filter=ctx.dgrad_filter, bias=bpad, out=zf)
+            z = zf[:, :co]
+            ctx.save_for_backward(xp.buf, weight)
+            ctx.mode = 'nobn_linear'
         else:
             wprep = prepared_filter(cfg['weight_param']) if (not cfg.get('grad', True) and f16 and fast_conv_shape(x.shape[1], k, s)
                                                               and os.environ.get('Y4_NO_INFER_CACHE') != '1'
@@ -953,7 +999,7 @@ class ConvBNActFn(torch.autograd.Function):
         cfg = ctx.cfg
         k, s, act = cfg['k'], cfg['s'], cfg['act']
         f16 = f16x2_mode() and ctx.x_shape[1] != 3
-        dy_amax = dy_pl = None
+        dy_amax = dy_pl = dyP = wq = None          # dyP / wq: pre-split dy and padded filter of a conv without BatchNorm over planes
         x_amax = live(ctx.x_amax)                     # None if the ring recycled it since forward: wgrad takes its own pass
         x_planes = getattr(ctx, 'x_planes', False)
         if ctx.mode in ('bn_train', 'bn_eval_grad'):
@@ -993,7 +1039,16 @@ class ConvBNActFn(torch.autograd.Function):
             dy = dz
             dgamma = dbeta = None
             dbias = bias_grad_raw(dz) if ctx.needs_input_grad[2] else None
-            if f16:
+            if x_planes:
+                # plane dgrad / wgrad want dy pre-split, over whole K tiles: the gradient with zero pad channels (a view of
+                # what yolo_decode_bwd wrote), one measuring pass (f16x2) and one split pass; the filter padded alike
+                bfp = planes_mode() == 'bf16'
+                q = 64 if bfp else 32
+                cop = (weight.shape[0] + q - 1) // q * q
+                dzp = _pad_channels_zero(dz, cop)
+                dyP = planes_split_raw(dzp, None if bfp else amax_raw(dzp))
+                wq = _pad_out_channels(weight, None, cop)[0]
+            elif f16:
                 dy_amax = amax_raw(dy)               # used by dgrad and wgrad: one pass instead of two
         else:
             raise Y4Error(f'backward through ConvBNAct in mode {ctx.mode} is not implemented')
@@ -1007,6 +1062,8 @@ class ConvBNActFn(torch.autograd.Function):
                 dx = conv_stem_dgrad_raw(dy, weight, x)       # gradient wrt the network input (never needed in training)
             # skip_grad: the gradient that reached this ResBlock unit over its skip connection, parked by the unit's
             # 3x3 conv (dres_put below): added in the dgrad epilogue instead of by a separate fan-in kernel
+            elif x_planes and dyP is not None:
+                dx = conv_dgrad_planes_raw(dyP, wq, ctx.x_shape, k, residual=skip_grad, prepared=getattr(ctx, 'dgrad_filter', None))
             elif x_planes and (s == 1 or not twin_dy):
                 dx = conv_dgrad_planes_raw(Planes(dy, dy.shape, dy_amax), weight, ctx.x_shape, k, residual=skip_grad,
                                            prepared=getattr(ctx, 'dgrad_filter', None), s=s)
@@ -1027,6 +1084,8 @@ class ConvBNActFn(torch.autograd.Function):
             param = cfg.get('weight_param')
 
             def wgrad(out=None):
+                if x_planes and dyP is not None:     # (dy's rows hold whole K tiles, dW the rows of the real output channels)
+                    return conv_wgrad_planes_raw(Planes(x, ctx.x_shape, ctx.x_amax), dyP, tuple(weight.shape), k, out=out)
                 if x_planes:
                     return conv_wgrad_planes_raw(Planes(x, ctx.x_shape, ctx.x_amax), Planes(dy_pl, dy.shape, dy_amax),
                                                  tuple(weight.shape), k, out=out, s=s)
@@ -1034,7 +1093,8 @@ class ConvBNActFn(torch.autograd.Function):
             if _ASYNC['on'] and param is not None and param.requires_grad:
                 # lands in param.grad on the side stream
                 # (the operand the side stream reads: for a stride-2 plane layer that is the pre-split twin of dy)
-                _wgrad_to_param(x, dy_pl if x_planes else dy, param, k, s, ctx.x_amax if x_planes else x_amax, dy_amax,
+                _wgrad_to_param(x, (dyP.buf if dyP is not None else dy_pl) if x_planes else dy, param, k, s,
+                                ctx.x_amax if x_planes else x_amax, dyP.amax if dyP is not None else dy_amax,
                                 fn=wgrad if x_planes else None)
             elif param is not None and getattr(param, '_y4_grad_fresh', False) and param.grad is not None:
                 # gradient slot owned by BucketedDDP and still zero in this window: the kernel writes it in place

@@ -200,7 +200,13 @@ class Head(nn.Module):
 
     def logits(self, p1, p2, p3):
         assert p1.shape[1] == 128 and p2.shape[1] == 256 and p3.shape[1] == 512
-        return [h[1](h[0](p)) for h, p in ((self.yolo1, p1), (self.yolo2, p2), (self.yolo3, p3))]
+        # the 3x3 conv's activation has ONE reader, the output conv: where that conv takes planes (training, ops.ConvBNActFn
+        # "a conv WITHOUT BatchNorm over a pre-split input") and nobody is looking, it leaves pre-split
+        out = []
+        for h, p in ((self.yolo1, p1), (self.yolo2, p2), (self.yolo3, p3)):
+            want = takes_planes(h[1], geo=geo_of(p)) and not observed(self, h, h[0], h[1])
+            out.append(h[1](h[0](p, out_planes=bool(want))))
+        return out
 
     def forward(self, p1, p2, p3):
         if observed(self.yolo1, self.yolo2, self.yolo3):
