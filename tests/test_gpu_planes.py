@@ -276,6 +276,16 @@ def test_bf16_planes_forward_dgrad_wgrad_are_exact_bf16_products(dev, bf16_mode,
             dw2 = ops.conv_wgrad_planes_raw(xp, ops.planes_split_raw(cl(dy2, dev)), (co, ci, k, k), k, s=2)
             ref2 = torch.nn.grad.conv2d_weight(_bf(x), (co, ci, k, k), _bf(dy2), 2, 1)
             assert float((dw2.double().cpu() - ref2).abs().max()) <= 2e-6 * float(ref2.abs().max())
+            # ... and dgrad: four parity-class launches of the bf16 forward-form kernel on the un-mirrored transposed filter,
+            # also on the planes the forward call prepares for a stride-2 layer
+            dyp2 = ops.planes_split_raw(cl(dy2, dev))
+            dx2 = ops.conv_dgrad_planes_raw(dyp2, wd, (B, ci, H, W), k, s=2)
+            assert ', true, false, true>' in ops.last_conv_kernel(), ops.last_conv_kernel()
+            dx_ref2 = torch.nn.grad.conv2d_input((B, ci, H, W), _bf(w), _bf(dy2), 2, 1)
+            assert float((dx2.double().cpu() - dx_ref2).abs().max()) <= 2e-6 * float(dx_ref2.abs().max())
+            buf = ops.dgrad_filter_buffer(ci, co, k, dev)
+            ops.conv_fwd_planes_raw(xp, wd, k, s, dgrad_filter=buf)
+            assert torch.equal(dx2, ops.conv_dgrad_planes_raw(dyp2, wd, (B, ci, H, W), k, s=2, prepared=buf))
         return
     dy = recipe.randn((B, co, H, W), 9)
     dyd = cl(dy, dev)

@@ -86,7 +86,7 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
                 const float* res, long long ldr, float* stats, int* nparts, int B, int Hs, int Ws, int Cs, int N, int k, int stride,
                 hipStream_t st, bool bf = false, bool dst_bf16 = false);
 int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_planes, const unsigned* wt_amax, float* dx, long long lddx,
-                    int B, int H, int W, int Cin, int Cout, hipStream_t st);
+                    int B, int H, int W, int Cin, int Cout, hipStream_t st, bool bf = false);
 int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st, bool bf = false);
 void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn = 128);
 int planes_wgrad_tn(int Cout, bool bf);

@@ -983,8 +983,8 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
 // dgrad of a 3x3 stride-2 conv over dy planes [B][Ho][Wo][Cout] (H = 2 Ho, W = 2 Wo): four forward-form launches, one per parity
 // class of the dx grid, each over its own 1 / 2 / 2 / 4 taps of the TRANSPOSED (un-mirrored) filter planes [Cin][9][Cout]
 int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_planes, const unsigned* wt_amax, float* dx, long long lddx,
-                    int B, int H, int W, int Cin, int Cout, hipStream_t st) {
-    if ((H & 1) || (W & 1) || (Cout & 31) || (Cin & 3)) return Y4_ERR_SHAPE;
+                    int B, int H, int W, int Cin, int Cout, hipStream_t st, bool bf) {
+    if ((H & 1) || (W & 1) || (Cout & 31) || (Cin & 3) || (bf && (Cout & 63))) return Y4_ERR_SHAPE;
     const int Ho = H / 2, Wo = W / 2;
     PlaneConvGeom g{};
     g.src = static_cast<const unsigned char*>(dy); g.wt = static_cast<const unsigned char*>(wt_planes);
@@ -995,7 +995,7 @@ int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_plan
     const long long M = (long long)B * Ho * Wo;
     g.M = (int)M; g.K = 9 * Cout;
     const unsigned long long img = (unsigned long long)Ho * Wo * (unsigned long long)Cout * 4ull;
-    const unsigned long long wb = (unsigned long long)Cin * g.K * 4ull;
+    const unsigned long long wb = (unsigned long long)Cin * g.K * (bf ? 2ull : 4ull);
     g.src_total_bytes = (unsigned long long)B * img;
     g.wt_bytes = (unsigned)wb;
     g.src_amax = dy_amax; g.wt_amax = wt_amax;
@@ -1009,7 +1009,8 @@ int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_plan
                 const int t = g.cls_ntaps++;
                 g.cls_dh[t] = (ph + 1 - r) / 2; g.cls_dw[t] = (pw + 1 - q) / 2; g.cls_slot[t] = r * 3 + q;
             }
-        const int rc = launch_conv_planes<256, 128, 4, 2, false, false, true>(g, st);
+        const int rc = bf ? launch_conv_planes<256, 128, 4, 2, true, false, true>(g, st)
+                          : launch_conv_planes<256, 128, 4, 2, false, false, true>(g, st);
         if (rc != Y4_OK) return rc;
     }
     return Y4_OK;
@@ -1168,10 +1169,8 @@ int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int
         if (reinterpret_cast<uintptr_t>(dgrad_filter) & 15) return Y4_ERR_SHAPE;
         unsigned* hdr_t = reinterpret_cast<unsigned*>(static_cast<char*>(dgrad_filter) + (size_t)Cin * k * k * Cout * 6);
         // stride 1: mirrored (the plane dgrad is the forward kernel); stride 2: as the register-staged dgrad wants them
-        // (bf16 forward at stride 2: the register-staged dgrad of that layer runs in the conv mode's own arithmetic and splits
-        // the filter itself -- the caller passes no dgrad_filter then)
-        if (bf && stride != 1) return Y4_ERR_SHAPE;
-        if (bf) rc = bf16_filter(w, planes, static_cast<unsigned short*>(dgrad_filter), Cout, Cin, k * k, true, st);
+        // (bf16 planes at stride 2: the un-mirrored transposed bf16 planes the bf16 parity-class dgrad takes)
+        if (bf) rc = bf16_filter(w, planes, static_cast<unsigned short*>(dgrad_filter), Cout, Cin, k * k, stride == 1, st);
         else rc = y4::f16x2_filter_planes_dual(w, planes, hdr, hdr + 16, static_cast<unsigned short*>(dgrad_filter), hdr_t, Cout, Cin, k * k,
                                                Cout, stride == 1, st);
     } else {
@@ -1196,8 +1195,8 @@ int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx,
     const bool bf = pl_bf();
     if (!bf && !dy_amax) return Y4_ERR_NULL;
     if (stride == 2) {
-        // 3x3 stride 2 on an even map (f16x2 operands): one launch per parity class on the un-mirrored transposed planes
-        if (bf || k != 3 || residual || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || !y4::planes_conv_ok(Cout, Cin, k, 1) ||
+        // 3x3 stride 2 on an even map: one launch per parity class on the un-mirrored transposed planes
+        if ((bf && (Cout & 63)) || k != 3 || residual || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || !y4::planes_conv_ok(Cout, Cin, k, 1) ||
             lddx < Cin || (lddx & 3)) return Y4_ERR_SHAPE;
         if (workspace_bytes < y4_conv2d_dgrad_workspace(Cin, Cout, k)) return Y4_ERR_WORKSPACE;
         if ((reinterpret_cast<uintptr_t>(dy_planes) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
@@ -1205,10 +1204,11 @@ int y4_conv2d_dgrad_planes_f32(const void* dy_planes, const float* w, float* dx,
         hipStream_t st2 = y4_stream(stream);
         unsigned* hdr2 = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + (size_t)Cin * 9 * Cout * 6);
         if (w) {
-            const int rc = y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, 9, Cout, hdr2, hdr2 + 16, st2, false);
+            const int rc = bf ? bf16_filter(w, nullptr, static_cast<unsigned short*>(workspace), Cout, Cin, 9, false, st2)
+                              : y4::f16x2_filter_planes_transposed(w, static_cast<unsigned short*>(workspace), Cout, Cin, 9, Cout, hdr2, hdr2 + 16, st2, false);
             if (rc != Y4_OK) return rc;
         }
-        return y4::planes_dgrad_s2(dy_planes, dy_amax, workspace, hdr2, dx, lddx, B, H, W, Cin, Cout, st2);
+        return y4::planes_dgrad_s2(dy_planes, dy_amax, workspace, hdr2, dx, lddx, B, H, W, Cin, Cout, st2, bf);
     }
     if (stride != 1) return Y4_ERR_SHAPE;
     if (B <= 0 || H <= 0 || W <= 0 || !y4::planes_conv_ok(Cout, Cin, k, 1) || lddx < Cin || (lddx & 3)) return Y4_ERR_SHAPE;

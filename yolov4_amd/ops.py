@@ -252,6 +252,14 @@ def planes_fit(B, H, W, ci, co, k, s, dgrad=True):
                        int(k), int(s), bool(dgrad))
 
 
+def s2_plane_dgrad(B, H, W, ci, co):
+    """Does the dgrad of a 3x3 stride-2 plane layer (x: [B, ci, H, W]) run on the plane kernel (four parity-class launches over a
+    pre-split dy)?  Not with fewer than 128 input channels (half-empty column tiles: 64->128 @304 took 1.81 ms there, 1.24 + 0.14
+    on the register-staged kernel over an fp32 twin of dy), nor when the whole dx tensor is beyond the kernel's one 32-bit
+    window.  Forward (which prepares the filter planes that dgrad will want) and backward ask the same question."""
+    return _S2_DGRAD_PLANES and ci >= 128 and planes_fit(B, H, W, ci, co, 3, 2, dgrad=True)
+
+
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
 _S2_DGRAD_PLANES = os.environ.get('Y4_PLANES_S2_DGRAD', '1') != '0'      # (A/B switch: 0 = register-staged stride-2 dgrad over an fp32 twin of dy)
 # bf16 conv RESULTS on the plane layers of conv mode 'bf16' (y4_conv2d_fwd_planes_f32 y_bf16; what autocast does to a conv's
@@ -895,7 +903,9 @@ class ConvBNActFn(torch.autograd.Function):
             ctx.dgrad_filter = None
             if ((f16 or (bfm and xp is not None)) and ctx.needs_input_grad[0] and x.shape[1] % 32 == 0 and fast_conv_shape(x.shape[1], k, s)
                     and weight.shape[0] % 4 == 0 and (xp is None or weight.shape[0] % 32 == 0)
-                    and not (bfm and xp is not None and s == 2)):    # (bf16 planes at stride 2: the f16x2 dgrad splits the filter itself)
+                    # (bf16 planes at stride 2 whose dgrad stays on the register-staged f16x2 kernel: that one splits the filter itself)
+                    and not (bfm and xp is not None and s == 2
+                             and not s2_plane_dgrad(x.shape[0], x.shape[2], x.shape[3], x.shape[1], weight.shape[0]))):
                 ctx.dgrad_filter = dgrad_filter_buffer(x.shape[1], weight.shape[0], k, x.device)
             # conv mode 'bf16': the plane conv writes y as bf16 (half the bytes for the three BatchNorm sweeps that read it)
             ybf = ctx.y_bf16 = bool(bfm and xp is not None and weight.shape[0] % 32 == 0 and _BF16_Y)
@@ -1018,9 +1028,8 @@ class ConvBNActFn(torch.autograd.Function):
             # (f16x2 operands: the plane kernel runs the stride-2 dgrad too, class by class -- no fp32 copy)
             # and not with fewer than 128 input channels (half-empty column tiles: 64->128 @304 took 1.81 ms there, 1.24 + 0.14 this way)
             # nor when the whole dx tensor is beyond the plane dgrad's one 32-bit window (planes_fit)
-            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and (
-                bfp or not _S2_DGRAD_PLANES or ctx.x_shape[1] < 128
-                or not planes_fit(ctx.x_shape[0], ctx.x_shape[2], ctx.x_shape[3], ctx.x_shape[1], dz.shape[1], k, s, dgrad=True))
+            twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and not s2_plane_dgrad(
+                ctx.x_shape[0], ctx.x_shape[2], ctx.x_shape[3], ctx.x_shape[1], dz.shape[1])
             res = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
                                  gp.grad if sink else None, bp.grad if sink else None,
                                  out_amax=None if planes is not None else dy_amax, planes=planes,
