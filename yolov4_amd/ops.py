@@ -257,7 +257,9 @@ def s2_plane_dgrad(B, H, W, ci, co):
     pre-split dy)?  Not with fewer than 128 input channels (half-empty column tiles: 64->128 @304 took 1.81 ms there, 1.24 + 0.14
     on the register-staged kernel over an fp32 twin of dy), nor when the whole dx tensor is beyond the kernel's one 32-bit
     window.  Forward (which prepares the filter planes that dgrad will want) and backward ask the same question."""
-    return _S2_DGRAD_PLANES and ci >= 128 and planes_fit(B, H, W, ci, co, 3, 2, dgrad=True)
+    # (bf16 operands: from 64 input channels on -- one MFMA per product makes the half-empty tiles cheap: 670.1 / 676.4 -> 679.5 / 679.7 img/s)
+    floor = 64 if planes_mode() == 'bf16' else 128
+    return _S2_DGRAD_PLANES and ci >= floor and planes_fit(B, H, W, ci, co, 3, 2, dgrad=True)
 
 
 _S2_PLANES = os.environ.get('Y4_PLANES_S2', '1') != '0'      # (A/B switch)
