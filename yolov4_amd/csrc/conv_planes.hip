@@ -82,6 +82,12 @@ __device__ __forceinline__ f32x4v pl_mma(const f16x8 a, const f16x8 b, const f32
 // the epilogue do not share one register allocation (as run-time branches they cost the 128 x 64 wave tile 14 spills)
 // DG2: the parity-class dgrad of the 3x3 stride-2 layers (PlaneConvGeom::cls_*): a tap list instead of the k x k raster, and a
 // scattered destination (every second pixel of every second row).
+// Cache policy of the result stores: nt (streaming).  The result of a conv is read once, by the BatchNorm sweep that follows
+// (itself with streaming loads), and is far larger than what the next K sweep of this kernel wants to find in the caches:
+// 449.2 / 450.1 / 448.2 -> 453.8 / 453.4 / 453.1 img/s (three A/B rounds on one box, forward + stride-1 dgrad epilogues).
+#ifndef PL_ST_POL
+#define PL_ST_POL 2
+#endif
 template <int BM, int BN, int WM, int WN, bool BF, bool YB = false, bool DG2 = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_planes_mfma(const PlaneConvGeom g) {
     constexpr int NWAVE = WM * WN, NTHR = NWAVE * 64;
@@ -353,7 +359,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                     for (int j = 0; j < TN; ++j) {
                         const float v = result(i, j, e);
                         const bool cok = rok && (allc || colb + 16 * j < g.N);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), xrs, (int)(cok ? po + 64u * j : 0xffffffffu), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), xrs, (int)(cok ? po + 64u * j : 0xffffffffu), 0, PL_ST_POL);
                     }
                     if (++wc == g.Wd) { wc = 0; if (++hc == g.Hd) { hc = 0; ++b; } }
                 }
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                             const float v = result(i, j, e0 + e);
                             acc0[i][j][e0 + e] = v;        // kept for the column sums
                             const bool cok = allc || colb + 16 * j < g.N;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rv[e][j]), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)((e0 + e) * drow), 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rv[e][j]), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)((e0 + e) * drow), PL_ST_POL);
                         }
                 }
             }
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                         const float v = result(i, j, e);
                         acc0[i][j][e] = v;                 // kept for the column sums
                         const bool cok = allc || colb + 16 * j < g.N;
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), drs, (int)(cok ? dvo + 64u * j : 0xffffffffu), (int)(e * drow), PL_ST_POL);
                     }
             }
         }
@@ -429,7 +435,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN == 8 ? 1 : 2) void conv_plane
                         csum[j] += vr; cssum[j] += vr * vr;
                         const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, true);   // lane ^ 1
                         const bool cok = (allc || colb + 16 * j < g.N) && !(fr & 1);
-                        __builtin_amdgcn_raw_buffer_store_b32((u >> 16) | nb, drs, (int)(cok ? dvo + 32u * j : 0xffffffffu), (int)(e * drow), 0);
+                        __builtin_amdgcn_raw_buffer_store_b32((u >> 16) | nb, drs, (int)(cok ? dvo + 32u * j : 0xffffffffu), (int)(e * drow), PL_ST_POL);
                     }
                 __builtin_amdgcn_sched_barrier(0);         // (one row tile at a time)
             }
