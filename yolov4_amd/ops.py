@@ -1025,11 +1025,9 @@ class ConvBNActFn(torch.autograd.Function):
             bfp = x_planes and planes_mode() == 'bf16'       # conv mode 2: dy leaves as plain bf16, no scale word
             planes = planes_cell(dz.device, 8) if (x_planes and not bfp) else None
             dy_amax = planes[5:6] if planes is not None else (new_amax(dz.device) if f16 else None)
-            # stride 2 over planes: wgrad runs on the plane kernel, dgrad on the register-staged parity-class kernel, which
-            # wants fp32 -- dy leaves the sweep both ways (the bound in word [5] dominates max|dy|: it serves both as scale)
-            # (f16x2 operands: the plane kernel runs the stride-2 dgrad too, class by class -- no fp32 copy)
-            # and not with fewer than 128 input channels (half-empty column tiles: 64->128 @304 took 1.81 ms there, 1.24 + 0.14 this way)
-            # nor when the whole dx tensor is beyond the plane dgrad's one 32-bit window (planes_fit)
+            # stride 2 over planes: wgrad runs on the plane kernel; dgrad too, class by class (s2_plane_dgrad) -- or, where that
+            # does not pay or does not fit, on the register-staged parity-class kernel, which wants fp32: dy then leaves the sweep
+            # both ways (the bound in word [5] dominates max|dy|: it serves both as scale)
             twin_dy = x_planes and s == 2 and ctx.needs_input_grad[0] and not s2_plane_dgrad(
                 ctx.x_shape[0], ctx.x_shape[2], ctx.x_shape[3], ctx.x_shape[1], dz.shape[1])
             res = bn_act_bwd_raw(dz, y, mean, invstd, gamma, beta, act,
