@@ -151,6 +151,11 @@ int y4_conv2d_fwd_bnstats_f32(const float* x, int ldx, const float* w, float* y,
  * y4_conv2d_fwd_planes_f32 = y4_conv2d_fwd_bnstats_f32 on such an input (raw output + per-M-tile column sums, 256- or 128-row tiles;
  * partials may be NULL); workspace as y4_conv2d_fwd_f32.  Replaces the same nn.Conv2d, darknet/darknet.py:31-36,53-54. */
 int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, void* stream);
+/* The same into a CHANNEL SLICE of a wider pre-split tensor (a concat buffer whose other slices their producers write pre-split,
+ * y4_bn_planes_bound_f32): `planes` points at the slice's first tile in pixel 0's row (128-B aligned; bf16 mode: byte 2 c of the
+ * row for channel offset c), ld_planes = channels per pixel row of the whole tensor; *amax = the tensor's joint scale word, which
+ * must dominate max|x|.  Replaces the copy half of torch.cat, yolo/model/yolov4.py:176,183 (PANBlock). */
+int y4_planes_split_into_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, int ld_planes, void* stream);
 int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,
                              int B, int H, int W, int Cin, int Cout, int k, int stride,
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,

@@ -345,3 +345,103 @@ def test_head_output_conv_without_batchnorm_over_a_pre_split_input(dev, mode, k)
         for p1, p0 in zip([o1, gx1] + gp1, [o0, gx0] + gp0):
             assert p1.shape == p0.shape
             assert float((p1 - p0).abs().mean()) <= 2e-2 * max(float(p0.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16'])
+def test_pan_concats_take_the_lateral_tensor_by_a_split_instead_of_a_copy(dev, mode):
+    """PANBlock (yolov4.py:160-189 in the reference): cat([down(p), f]) -- the stride-2 conv writes its slot of the concat buffer
+    pre-split, the lateral fp32 tensor f is SPLIT into the other slot (y4_planes_split_into_f32) under the joint scale
+    max(bound of the conv's BatchNorm, max|f|); the concat-fed 1x1 conv then runs on the DMA kernels.  Against the switch off."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd.darknet import darknet as D
+    from yolov4_amd.yolo.model.yolov4 import PANBlock
+    torch.manual_seed(15)
+    blk = PANBlock().to(dev).train()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+        if isinstance(m, D.ConvBNAct):
+            m.act_name = 'mish'                      # (smooth activation: see the FPN test)
+    h = 10
+    xs = [(3.0 * torch.randn(2, c, h * f, h * f, device=dev)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for c, f in ((128, 4), (256, 2), (512, 1))]           # (laterals with a range well above the BatchNorm outputs')
+    ws = [torch.randn(2, c, h * f, h * f, device=dev).contiguous(memory_format=torch.channels_last) for c, f in ((128, 4), (256, 2), (512, 1))]
+
+    def run(on):
+        D._CAT_PLANES = on
+        for p in blk.parameters():
+            p.grad = None
+        for x in xs:
+            x.grad = None
+        outs = blk(*xs)
+        sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], [x.grad.clone() for x in xs], [p.grad.clone() for p in blk.parameters()]
+    was, old_mode = D._CAT_PLANES, yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode(mode)
+        assert blk._cat_planes(blk.conv1, blk.module1, xs[1]) is not None
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+    finally:
+        D._CAT_PLANES = was
+        yolov4_amd.set_conv_mode(old_mode)
+    if mode == 'f16x2':
+        for a, b in zip(o1, o0):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+        for a, b in zip(gx1 + gp1, gx0 + gp0):
+            assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-6)
+    else:
+        for a, b in zip(o1 + gx1 + gp1, o0 + gx0 + gp0):
+            assert float((a - b).abs().mean()) <= 2e-2 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize('mode', ['f16x2', 'bf16'])
+def test_spp_concat_leaves_pre_split_for_its_conv(dev, mode):
+    """SPPBlock (yolov4.py:52-77 in the reference): cat([pool5, pool9, pool5, x]) has one reader, the 1x1 conv 2048 -> 512: the
+    concatenated tensor is split once (scale: the maximum of x, which pooling cannot exceed) and the conv runs on the DMA
+    kernels.  Against the switch off."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd.darknet import darknet as D
+    from yolov4_amd.yolo.model.yolov4 import SPPBlock
+    torch.manual_seed(19)
+    blk = SPPBlock().to(dev).train()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+        if isinstance(m, D.ConvBNAct):
+            m.act_name = 'mish'                      # (smooth activation: see the FPN test)
+    x = torch.randn(3, 1024, 13, 13, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(3, 512, 13, 13, device=dev).contiguous(memory_format=torch.channels_last)
+    seen = []
+
+    def run(on):
+        D._CAT_PLANES = on
+        for p in blk.parameters():
+            p.grad = None
+        x.grad = None
+        out = blk(x)
+        seen.append(ops.last_conv_kernel())
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blk.parameters()]
+    was, old_mode = D._CAT_PLANES, yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode(mode)
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+    finally:
+        D._CAT_PLANES = was
+        yolov4_amd.set_conv_mode(old_mode)
+    assert 'conv_planes_mfma' in seen[0] and 'conv_planes_mfma' not in seen[1], seen
+    if mode == 'f16x2':
+        assert float((o1 - o0).abs().max()) <= 2e-5 * float(o0.abs().max())
+        for a, b in zip([gx1] + gp1, [gx0] + gp0):
+            assert float((a - b).abs().max()) <= 3e-4 * max(float(b.abs().max()), 1e-6)
+    else:
+        for a, b in zip([o1, gx1] + gp1, [o0, gx0] + gp0):
+            assert float((a - b).abs().mean()) <= 2e-2 * max(float(b.abs().max()), 1e-6)

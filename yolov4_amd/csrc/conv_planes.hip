@@ -791,7 +791,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
 
 // ---- fp32 NHWC (pitch ld) -> planes; one thread per 4 channels of a pixel
 __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restrict__ x, long long ld, long long M, int C,
-                                                           const unsigned* __restrict__ amax, unsigned char* __restrict__ planes) {
+                                                           const unsigned* __restrict__ amax, unsigned char* __restrict__ planes,
+                                                           long long pitch) {
     const float s = pl_scale(amax);
     const int C4 = C >> 2;
     const long long total = M * C4;
@@ -807,7 +808,7 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
             hi[e] = (_Float16)t;
             lo[e] = (_Float16)((t - (float)hi[e]) * 2048.f);
         }
-        unsigned char* row = planes + m * (long long)C * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        unsigned char* row = planes + m * pitch + (c >> 5) * 128 + (c & 31) * 2;
         *reinterpret_cast<h4*>(row) = hi;
         *reinterpret_cast<h4*>(row + 64) = lo;
     }
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
 // row (pitch 4 C bytes: same allocation, same addressing as the f16x2 planes; the second half is never touched)
 __device__ __forceinline__ unsigned short pl_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 __global__ __launch_bounds__(256) void planes_split_bf16_kernel(const float* __restrict__ x, long long ld, long long M, int C,
-                                                                unsigned char* __restrict__ planes) {
+                                                                unsigned char* __restrict__ planes, long long pitch) {
     const int C4 = C >> 2;
     const long long total = M * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -828,7 +829,7 @@ __global__ __launch_bounds__(256) void planes_split_bf16_kernel(const float* __r
         us4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pl_bf16_bits(v[e]);
-        *reinterpret_cast<us4*>(planes + m * (long long)C * 4 + c * 2) = o;
+        *reinterpret_cast<us4*>(planes + m * pitch + c * 2) = o;
     }
 }
 // filter [Cout][kk][Cin] fp32 -> bf16, same order (forward operand), and optionally [Cin][kk (mirrored)][Cout] (dgrad operand)
@@ -1104,16 +1105,20 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     return Y4_OK;
 }
 
-int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st, bool bf) {
+int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st, bool bf,
+                 long long pitch_ch) {
+    // pitch_ch: channels per pixel row of the destination (0: C, dense; > C: a channel slice of a wider pre-split tensor)
+    const long long pitch = (pitch_ch > 0 ? pitch_ch : (long long)C) * 4;
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (bf) {
-        hipLaunchKernelGGL(planes_split_bf16_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C, static_cast<unsigned char*>(planes));
+        hipLaunchKernelGGL(planes_split_bf16_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C,
+                           static_cast<unsigned char*>(planes), pitch);
         Y4_CHECK_LAUNCH();
         return Y4_OK;
     }
     hipLaunchKernelGGL(planes_split_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C, amax,
-                       static_cast<unsigned char*>(planes));
+                       static_cast<unsigned char*>(planes), pitch);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -1144,6 +1149,14 @@ int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsig
     if (pl_bf() && (C & 63)) return Y4_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 15)) return Y4_ERR_SHAPE;
     return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream), pl_bf());
+}
+
+int y4_planes_split_into_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, int ld_planes, void* stream) {
+    if (!x || !planes || (!amax && !pl_bf())) return Y4_ERR_NULL;
+    if (M <= 0 || C <= 0 || (C & 31) || ldx < C || (ldx & 3) || ld_planes < C || (ld_planes & 31)) return Y4_ERR_SHAPE;
+    if (pl_bf() && (C & 63)) return Y4_ERR_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 127)) return Y4_ERR_SHAPE;
+    return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream), pl_bf(), ld_planes);
 }
 
 int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,

@@ -1196,6 +1196,11 @@ class CatBuffer:
             if pm == 'f16x2':
                 self.cell = planes_cell(device)
                 for i, n in enumerate(planes_norms):
+                    if isinstance(n, torch.Tensor) and not isinstance(n, torch.nn.Module):
+                        # an EXISTING fp32 tensor that cat() will split into its slot (PANBlock: the lateral input): its maximum
+                        c = live(amax_of(n))
+                        amax_merge(self.cell[0:1], c if c is not None else amax_raw(n))
+                        continue
                     # (norm, M): a producer whose BatchNorm ran over M pixels of its own (the layer in front of an Upsample)
                     n, M = n if isinstance(n, tuple) else (n, B * H * W)
                     check(lib().y4_bn_planes_bound_f32(_ptr(n.weight), _ptr(n.bias), self.sizes[i], M,
@@ -1208,6 +1213,17 @@ class CatBuffer:
         if self.planes:
             t.y4_cat = self                          # ConvBNActFn writes its activation here pre-split (cfg 'out_cat')
         return t
+
+
+def _split_into_slot(t, dst, cb):
+    """fp32 NHWC tensor t -> the slot `dst` (a channel slice of cb.buf) of a pre-split CatBuffer, in the buffer's plane form."""
+    B, C, H, W = t.shape
+    t, ldt = as_nhwc(t)
+    zp = dst.data_ptr()
+    if planes_mode() == 'bf16':                      # bf16 rows: channel c of the concat sits at byte 2 c of the pixel row
+        zp = cb.buf.data_ptr() + (zp - cb.buf.data_ptr()) // 2
+    check(lib().y4_planes_split_into_f32(_ptr(t), ldt, B * H * W, C, _ptr(cb.cell[0:1]) if cb.cell is not None else None,
+                                         ctypes.c_void_p(zp), nhwc_pitch(dst), _stream()), 'planes_split_into')
 
 
 class CatFn(torch.autograd.Function):
@@ -1227,8 +1243,11 @@ class CatFn(torch.autograd.Function):
             dst = out[:, o:o + t.shape[1]]
             if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride()):
                 if into is not None and into.planes:
-                    raise Y4Error('a pre-split concat buffer takes only inputs its producers wrote in place')
-                copy_into_raw(t, dst)
+                    if getattr(t, 'y4_planes', False):
+                        raise Y4Error('a pre-split concat buffer takes pre-split inputs only where their producers wrote them in place')
+                    _split_into_slot(t, dst, into)   # an fp32 input: split (instead of copied) under the buffer's joint scale
+                else:
+                    copy_into_raw(t, dst)
             elif into is not None and into.planes != bool(getattr(t, 'y4_planes', False)):
                 raise Y4Error('concat buffer and input disagree on the pre-split form')
             o += t.shape[1]
@@ -1269,7 +1288,9 @@ class SppPoolCatFn(torch.autograd.Function):
     max_pool3 (13) is constructed but never used."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, cell=None):
+        """cell: planes mode (spp_pool_cat planes=True) -- the result leaves PRE-SPLIT for a conv on the DMA kernels (one split pass
+        over the concatenated tensor; f16x2: scaled by *cell, the maximum of x, which pooling cannot exceed)."""
         L = lib()
         _require_gpu(x, 'SPP input')
         B, C, H, W = x.shape
@@ -1286,6 +1307,10 @@ class SppPoolCatFn(torch.autograd.Function):
         copy_into_raw(x, out[:, 3 * C:4 * C])
         ctx.idx = (idx5, idx9)
         ctx.shape = (B, C, H, W)
+        if cell is not None:
+            pl = empty_nhwc(B, 4 * C, H, W, x.device)
+            check(L.y4_planes_split_f32(_ptr(out), ldo, B * H * W, 4 * C, _ptr(cell.t), _ptr(pl), st), 'planes_split(spp)')
+            return pl
         return out
 
     @staticmethod
@@ -1300,11 +1325,22 @@ class SppPoolCatFn(torch.autograd.Function):
         copy_into_raw(g[:, 3 * C:4 * C], dx)
         for sl, idx, ks in ((g[:, 0:C], idx5, 5), (g[:, C:2 * C], idx9, 9), (g[:, 2 * C:3 * C], idx5, 5)):
             check(L.y4_maxpool_s1_bwd_f32(_ptr(sl), ldg, _ptr(idx), _ptr(dx), ldx, 1, B, H, W, C, ks, st), 'maxpool_bwd')
-        return dx
+        return dx, None
 
 
-def spp_pool_cat(x):
-    """cat([pool5(x), pool9(x), pool5(x), x]); max|out| = max|x| (pooling selects elements)."""
+def spp_pool_cat(x, planes=False):
+    """cat([pool5(x), pool9(x), pool5(x), x]); max|out| = max|x| (pooling selects elements).  planes: the result leaves
+    pre-split for its one consumer, a conv on the DMA kernels (one extra split pass; needs 4 C to be whole K tiles)."""
+    pm = planes_mode()
+    if planes and pm is not None and x.is_cuda and (4 * x.shape[1]) % (64 if pm == 'bf16' else 32) == 0:
+        cell = None
+        if pm == 'f16x2':
+            # the scale word lives with the pre-split tensor (ring cells are recycled): a copy of x's maximum
+            cell = planes_cell(x.device)
+            src = live(amax_of(x))
+            amax_merge(cell[0:1], src if src is not None else amax_raw(x))
+        out = SppPoolCatFn.apply(x, Slot(cell[0:1]) if cell is not None else Slot(None))
+        return as_planes(out, cell[0:1] if cell is not None else None)
     return tag_amax(SppPoolCatFn.apply(x), amax_of(x))
 
 

@@ -63,7 +63,11 @@ class SPPBlock(nn.Module):
 
     def forward(self, x, out_planes=False):
         """out_planes: the sole consumer (fpn.module1[0]) takes a pre-split input; the reference has no such argument."""
-        return self.conv2(ops.spp_pool_cat(chain(self.conv1, x)), out_planes=soft(out_planes, self))
+        y = chain(self.conv1, x)
+        from ...darknet import darknet as D
+        # the pooled concat has one reader, conv2: where that takes planes and nobody is looking it is split once, pre-split
+        want = bool(D._CAT_PLANES and takes_planes(self.conv2, geo=geo_of(y)) and not observed(self, self.conv1, self.conv2))
+        return self.conv2(ops.spp_pool_cat(y, planes=want), out_planes=soft(out_planes, self))
 
 
 class Upsample(nn.Module):
@@ -154,17 +158,30 @@ class PANBlock(nn.Module):
     def forward(self, f1, f2, f3, head_planes=(False, False)):
         """head_planes: head.yolo2[0] / head.yolo3[0] take a pre-split input (p2 has a second, fp32 consumer; p3 none)."""
         p1, f1b = ops.fork(f1)
-        cb = ops.cat_buffer(f2, [256, f2.shape[1]])
+        cb = ops.cat_buffer(f2, [256, f2.shape[1]], planes_norms=self._cat_planes(self.conv1, self.module1, f2))
         p2 = self.conv1(f1b, out=cb.slot(0))
         assert p2.shape[2:] == f2.shape[2:]
         p2 = chain(self.module1, ops.cat([p2, f2], into=cb),
                    last='both' if (head_planes[0] or takes_planes(self.conv7, p2.shape[2:], geo_of(p2))) else False)
         p2a, p2b = ops.fork(p2)
-        cb = ops.cat_buffer(f3, [512, f3.shape[1]])
+        cb = ops.cat_buffer(f3, [512, f3.shape[1]], planes_norms=self._cat_planes(self.conv7, self.module2, f3))
         p3 = self.conv7(p2a, out=cb.slot(0))
         assert p3.shape[2:] == f3.shape[2:]
         p3 = chain(self.module2, ops.cat([p3, f3], into=cb), last=soft(head_planes[1], self))
         return p1, p2b, p3
+
+
+    def _cat_planes(self, down, five, f):
+        """planes_norms for the concat [down(.) | f] in front of the block `five`, or None: where its first conv takes planes and
+        nobody is looking, the stride-2 conv writes its slot of the concat buffer pre-split and cat() SPLITS the lateral
+        tensor f into the other slot (instead of copying it), both under one joint scale (darknet._CAT_PLANES, ops.CatBuffer)."""
+        from ...darknet import darknet as D
+        pm = ops.planes_mode()
+        if not (D._CAT_PLANES and pm is not None and takes_planes(five[0], geo=geo_of(f)) and down.training and down.has_bn
+                and not getattr(f, 'y4_planes', False) and f.shape[1] % (64 if pm == 'bf16' else 32) == 0
+                and not observed(self, down, five, five[0])):
+            return None
+        return (down.norm, f)
 
 
 class Neck(nn.Module):
