@@ -154,8 +154,10 @@ int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsig
 /* The same into a CHANNEL SLICE of a wider pre-split tensor (a concat buffer whose other slices their producers write pre-split,
  * y4_bn_planes_bound_f32): `planes` points at the slice's first tile in pixel 0's row (128-B aligned; bf16 mode: byte 2 c of the
  * row for channel offset c), ld_planes = channels per pixel row of the whole tensor; *amax = the tensor's joint scale word, which
- * must dominate max|x|.  Replaces the copy half of torch.cat, yolo/model/yolov4.py:176,183 (PANBlock). */
-int y4_planes_split_into_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, int ld_planes, void* stream);
+ * must dominate max|x|.  c_valid (0: C): source channels >= c_valid are PAD of x's rows (ldx >= C) and leave as zeros -- the
+ * 255-channel head gradient as 256 pre-split channels.  Replaces the copy half of torch.cat, yolo/model/yolov4.py:176,183 (PANBlock). */
+int y4_planes_split_into_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, int ld_planes, int c_valid,
+                             void* stream);
 int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,
                              int B, int H, int W, int Cin, int Cout, int k, int stride,
                              float* partials, size_t partial_bytes, long long* nparts_host, const unsigned* x_amax,

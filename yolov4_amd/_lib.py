@@ -43,7 +43,7 @@ PROTOTYPES = {
     'y4_conv2d_bnstats_workspace': (Z, [I, I, I, I, I, I, I]),
     'y4_conv2d_fwd_bnstats_f32': (I, [P, I, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P, Z, P, Z, P]),
     'y4_planes_split_f32': (I, [P, I, L, I, P, P, P]),
-    'y4_planes_split_into_f32': (I, [P, I, L, I, P, P, I, P]),
+    'y4_planes_split_into_f32': (I, [P, I, L, I, P, P, I, I, P]),
     'y4_conv2d_fwd_planes_f32': (I, [P, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, P, Z, P, Z, I, P, P]),
     'y4_conv2d_dgrad_planes_f32': (I, [P, P, P, I, I, I, I, I, I, I, I, P, Z, P, P, I, P]),
     'y4_conv2d_wgrad_planes_workspace': (Z, [I, I, I, I, I, I, I]),

@@ -792,7 +792,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_planes_mfma(const PlaneWgradGeom
 // ---- fp32 NHWC (pitch ld) -> planes; one thread per 4 channels of a pixel
 __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restrict__ x, long long ld, long long M, int C,
                                                            const unsigned* __restrict__ amax, unsigned char* __restrict__ planes,
-                                                           long long pitch) {
+                                                           long long pitch, int cvalid) {
     const float s = pl_scale(amax);
     const int C4 = C >> 2;
     const long long total = M * C4;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
         h4 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float t = v[e] * s;
+            const float t = c + e < cvalid ? v[e] * s : 0.f;   // (channels >= cvalid: pad of the source rows, written as zeros)
             hi[e] = (_Float16)t;
             lo[e] = (_Float16)((t - (float)hi[e]) * 2048.f);
         }
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
 // row (pitch 4 C bytes: same allocation, same addressing as the f16x2 planes; the second half is never touched)
 __device__ __forceinline__ unsigned short pl_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 __global__ __launch_bounds__(256) void planes_split_bf16_kernel(const float* __restrict__ x, long long ld, long long M, int C,
-                                                                unsigned char* __restrict__ planes, long long pitch) {
+                                                                unsigned char* __restrict__ planes, long long pitch, int cvalid) {
     const int C4 = C >> 2;
     const long long total = M * C4;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void planes_split_bf16_kernel(const float* __r
         typedef unsigned short us4 __attribute__((ext_vector_type(4)));
         us4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = pl_bf16_bits(v[e]);
+        for (int e = 0; e < 4; ++e) o[e] = c + e < cvalid ? pl_bf16_bits(v[e]) : (unsigned short)0;
         *reinterpret_cast<us4*>(planes + m * pitch + c * 2) = o;
     }
 }
@@ -1106,19 +1106,20 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
 }
 
 int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st, bool bf,
-                 long long pitch_ch) {
+                 long long pitch_ch, int c_valid) {
+    // c_valid (0: C): source channels >= c_valid are pad (whatever the rows hold there) and leave as zeros
     // pitch_ch: channels per pixel row of the destination (0: C, dense; > C: a channel slice of a wider pre-split tensor)
     const long long pitch = (pitch_ch > 0 ? pitch_ch : (long long)C) * 4;
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (bf) {
         hipLaunchKernelGGL(planes_split_bf16_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C,
-                           static_cast<unsigned char*>(planes), pitch);
+                           static_cast<unsigned char*>(planes), pitch, c_valid > 0 ? c_valid : C);
         Y4_CHECK_LAUNCH();
         return Y4_OK;
     }
     hipLaunchKernelGGL(planes_split_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, x, ld, M, C, amax,
-                       static_cast<unsigned char*>(planes), pitch);
+                       static_cast<unsigned char*>(planes), pitch, c_valid > 0 ? c_valid : C);
     Y4_CHECK_LAUNCH();
     return Y4_OK;
 }
@@ -1151,12 +1152,13 @@ int y4_planes_split_f32(const float* x, int ldx, long long M, int C, const unsig
     return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream), pl_bf());
 }
 
-int y4_planes_split_into_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, int ld_planes, void* stream) {
+int y4_planes_split_into_f32(const float* x, int ldx, long long M, int C, const unsigned* amax, void* planes, int ld_planes, int c_valid,
+                             void* stream) {
     if (!x || !planes || (!amax && !pl_bf())) return Y4_ERR_NULL;
-    if (M <= 0 || C <= 0 || (C & 31) || ldx < C || (ldx & 3) || ld_planes < C || (ld_planes & 31)) return Y4_ERR_SHAPE;
+    if (M <= 0 || C <= 0 || (C & 31) || ldx < C || (ldx & 3) || ld_planes < C || (ld_planes & 31) || c_valid < 0 || c_valid > C) return Y4_ERR_SHAPE;
     if (pl_bf() && (C & 63)) return Y4_ERR_SHAPE;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(planes) & 127)) return Y4_ERR_SHAPE;
-    return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream), pl_bf(), ld_planes);
+    return y4::planes_split(x, ldx, M, C, amax, planes, y4_stream(stream), pl_bf(), ld_planes, c_valid);
 }
 
 int y4_conv2d_fwd_planes_f32(const void* x_planes, const float* w, float* y, int ldy,

@@ -844,19 +844,19 @@ def _pad_out_channels(weight, bias, cop):
     return wp, bp
 
 
-def _pad_channels_zero(t, cop):
-    """NHWC tensor [B, C, H, W] as [B, cop, H, W] with ZERO pad channels: the same memory when its pixel pitch already is cop
-    (the head gradients leave yolo_decode_bwd that way), else a copy."""
+def _split_padded(t, cop, amax=None):
+    """Planes [B, cop, H, W] of the NHWC gradient t [B, C, H, W], C <= cop: channels C .. cop - 1 leave as zeros.  Reads the pad
+    of t's rows where its pixel pitch covers cop channels (the head gradients leave yolo_decode_bwd with pitch 256) -- never
+    writes it: the memory behind a gradient's logical channels need not be ours -- else goes through a padded copy."""
     B, C, H, W = t.shape
     t, ld = as_nhwc(t)
-    if ld == cop:
-        v = torch.as_strided(t, (B, cop, H, W), (H * W * cop, 1, W * cop, cop), t.storage_offset())
-    else:
+    if ld < cop:
         v = empty_nhwc(B, cop, H, W, t.device)
         v[:, :C].copy_(t)
-    if cop > C:
-        v[:, C:].zero_()
-    return v
+        t, ld = v, nhwc_pitch(v)
+    buf = torch.empty((B, H, W, cop * 4), dtype=torch.uint8, device=t.device)
+    check(lib().y4_planes_split_into_f32(_ptr(t), ld, B * H * W, cop, _ptr(amax), _ptr(buf), cop, C, _stream()), 'planes_split(padded)')
+    return Planes(buf, (B, cop, H, W), amax)
 
 
 # ------------------------------------------------------------------ autograd functions
@@ -1054,8 +1054,7 @@ class ConvBNActFn(torch.autograd.Function):
                 bfp = planes_mode() == 'bf16'
                 q = 64 if bfp else 32
                 cop = (weight.shape[0] + q - 1) // q * q
-                dzp = _pad_channels_zero(dz, cop)
-                dyP = planes_split_raw(dzp, None if bfp else amax_raw(dzp))
+                dyP = _split_padded(dz, cop, None if bfp else amax_raw(dz))
                 wq = _pad_out_channels(weight, None, cop)[0]
             elif f16:
                 dy_amax = amax_raw(dy)               # used by dgrad and wgrad: one pass instead of two
@@ -1223,7 +1222,7 @@ def _split_into_slot(t, dst, cb):
     if planes_mode() == 'bf16':                      # bf16 rows: channel c of the concat sits at byte 2 c of the pixel row
         zp = cb.buf.data_ptr() + (zp - cb.buf.data_ptr()) // 2
     check(lib().y4_planes_split_into_f32(_ptr(t), ldt, B * H * W, C, _ptr(cb.cell[0:1]) if cb.cell is not None else None,
-                                         ctypes.c_void_p(zp), nhwc_pitch(dst), _stream()), 'planes_split_into')
+                                         ctypes.c_void_p(zp), nhwc_pitch(dst), 0, _stream()), 'planes_split_into')
 
 
 class CatFn(torch.autograd.Function):
