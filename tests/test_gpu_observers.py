@@ -445,3 +445,50 @@ def test_spp_concat_leaves_pre_split_for_its_conv(dev, mode):
     else:
         for a, b in zip([o1, gx1] + gp1, [o0, gx0] + gp0):
             assert float((a - b).abs().mean()) <= 2e-2 * max(float(b.abs().max()), 1e-6)
+
+
+def test_bf16_mode_runs_the_64_channel_1x1_layers_of_stage_1_on_the_plane_kernels(dev):
+    """darknet._BF16_N64 (conv mode 'bf16' only): CSPDownSample0's split convs, its transition and the conv behind its residual unit
+    are 1x1 layers with 64 output channels -- half a column tile -- and run on the bf16 plane kernels all the same, so that their
+    activations, gradients and conv results pass the BatchNorm sweeps as bf16.  Against the switch off (fp32-grade kernels):
+    a bf16-grade difference; in the fp32-grade mode the switch changes nothing."""
+    import yolov4_amd
+    from yolov4_amd import ops
+    from yolov4_amd.darknet import darknet as D
+    torch.manual_seed(23)
+    blk = D.CSPDownSample0(32, 64, 3, 2).to(dev).train()
+    for m in blk.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            nn.init.uniform_(m.weight, 0.8, 1.2)
+            nn.init.normal_(m.bias, 0, 0.1)
+    x = torch.randn(2, 32, 48, 48, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = torch.randn(2, 64, 24, 24, device=dev).contiguous(memory_format=torch.channels_last)
+    seen = []
+
+    def run(on):
+        D._BF16_N64 = on
+        for p in blk.parameters():
+            p.grad = None
+        x.grad = None
+        out = blk(x)
+        seen.append(ops.last_conv_kernel())          # the transition conv
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blk.parameters()]
+    was, old_mode = D._BF16_N64, yolov4_amd.get_conv_mode()
+    try:
+        yolov4_amd.set_conv_mode('bf16')
+        assert D.takes_planes(blk.part1) and D.takes_planes(blk.transition) and not D.takes_planes(blk.part2_1_2[0])
+        o1, gx1, gp1 = run(True)
+        o0, gx0, gp0 = run(False)
+        yolov4_amd.set_conv_mode('f16x2')
+        assert not D.takes_planes(blk.part1)
+        f1 = run(True)
+        f0 = run(False)
+    finally:
+        D._BF16_N64 = was
+        yolov4_amd.set_conv_mode(old_mode)
+    assert 'conv_planes_mfma' in seen[0] and 'conv_planes_mfma' not in seen[1], seen
+    for a, b in zip([o1, gx1] + gp1, [o0, gx0] + gp0):
+        assert float((a - b).abs().mean()) <= 2e-2 * max(float(b.abs().max()), 1e-6)
+    assert torch.equal(f1[0], f0[0]) and torch.equal(f1[1], f0[1])

@@ -133,11 +133,16 @@ def takes_planes(m, hw=None, geo=None):
     if m.stride != 1 and not (hw is not None and ops.planes_stride2_ok(m.kernel_size, m.stride, int(hw[0]), int(hw[1]))):
         return False
     ci, co = m.conv.in_channels, m.conv.out_channels
-    if ci % 32 or co % 32 or co < 128 or ci < 64 or m.kernel_size not in (1, 3):
+    pm = ops.planes_mode()
+    # at least one full 128-column tile of output channels -- except the 1x1 layers with 64 output channels in the bf16 mode
+    # (stage 1 / 2: split convs, transition, the 1x1 of the stage-2 residual units): one MFMA per product makes the half-empty
+    # tile cheap, and what counts there is bytes -- bf16 activations, gradients and conv results through the BatchNorm sweeps
+    # (699 -> 716 img/s with the 128 -> 64 layers, -> 727 with the 64 -> 64 ones; the 3x3 64 -> 64 layers: +-0, left alone)
+    co_min = 64 if (pm == 'bf16' and _BF16_N64 and m.kernel_size == 1 and m.stride == 1) else 128
+    if ci % 32 or co % 32 or co < co_min or ci < 64 or m.kernel_size not in (1, 3):
         return False
     if not (ops.PLANES['on'] and m.conv.weight.is_cuda):
         return False
-    pm = ops.planes_mode()
     if not (pm == 'f16x2' or (pm == 'bf16' and ci % 64 == 0 and co % 64 == 0)):  # bf16 rows hold 64 channels
         return False
     # stride 2: backward picks the register-staged dgrad by itself when the plane one does not fit (ConvBNActFn.backward)
@@ -147,6 +152,8 @@ def takes_planes(m, hw=None, geo=None):
 # The head's output convs (no BatchNorm, bias, linear; yolo/model/yolov4.py:235-251 in the reference) over a pre-split input
 # (Y4_HEAD_PLANES=0: off)
 _HEAD_PLANES = os.environ.get('Y4_HEAD_PLANES', '1') != '0'
+# bf16 mode: the 1x1 layers with 64 output channels on the plane kernels too (Y4_BF16_N64=0: off)
+_BF16_N64 = os.environ.get('Y4_BF16_N64', '1') != '0'
 
 
 def _nobn_takes_planes(m, geo):
@@ -271,11 +278,19 @@ class CSPDownSample0(nn.Module):
     def forward(self, x, readers=None):
         """readers: the ConvBNAct modules that will read the result (the reference's forward has no such argument): where they
         take pre-split inputs the transition conv writes its result that way."""
-        xa, xb = ops.fork(self.base(x))
-        cb = ops.cat_buffer(xa, [self.part2_2.conv.out_channels, self.part1.conv.out_channels])
+        go = geo_of(x, self.base)
+        both = soft(bool(_TWIN_RES and takes_planes(self.part1, geo=go) and takes_planes(self.part2_1_1, geo=go)),
+                    self.part1, self.part2_1_1)
+        xa, xb = ops.fork(self.base(x, out_planes=both))
+        # (the concat in front of the transition conv pre-split where that conv takes planes: as CSPDownSample.forward)
+        cat_planes = (_CAT_PLANES and takes_planes(self.transition, geo=geo_of(xa)) and self.part1.training and self.part2_2.training
+                      and self.part1.has_bn and self.part2_2.has_bn
+                      and not observed(self, self.part1, self.part2_2, self.transition))
+        cb = ops.cat_buffer(xa, [self.part2_2.conv.out_channels, self.part1.conv.out_channels],
+                            planes_norms=(self.part2_2.norm, self.part1.norm) if cat_planes else None)
         fb = fork_box(xa, self.part1, self.part2_1_1)
         x1 = self.part1(xa, out=cb.slot(1), dres_take=fb)
-        x2 = res_unit(self.part2_1_2, self.part2_1_1(xb, dx_put=fb))
+        x2 = res_unit(self.part2_1_2, self.part2_1_1(xb, dx_put=fb), out_planes=soft(takes_planes(self.part2_2, geo=go), self.part2_2))
         x2 = self.part2_2(x2, out=cb.slot(0))
         return self.transition(ops.cat([x2, x1], into=cb), out_planes=soft(plan_for(readers, xa.shape[2:], xa.shape[0]), self) if readers else False)
 
