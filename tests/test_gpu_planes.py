@@ -227,6 +227,9 @@ BF16_CASES = [
     (2, 2048, 512, 1, 1, 5, 5),
     (3, 256, 512, 3, 1, 19, 19),       # 256 x 256 tiles, ragged M = 1083
     (2, 64, 192, 1, 1, 20, 20),        # N not a multiple of 128
+    (2, 64, 64, 1, 1, 256, 256),       # M = 131 072: the bf16 STREAMING 1x1 kernel (K = N = 64), forward and dgrad
+    (1, 128, 64, 1, 1, 368, 368),      # ... K = 128 forward / K = 64, N = 128 dgrad; ragged M = 135 424
+    (2, 64, 128, 1, 1, 258, 256),      # ... N = 128
 ]
 
 
@@ -262,7 +265,9 @@ def test_bf16_planes_forward_dgrad_wgrad_are_exact_bf16_products(dev, bf16_mode,
     assert xp.amax is None
     y, part, n = ops.conv_fwd_planes_raw(xp, wd, k, s)
     torch.cuda.synchronize()
-    assert ', true, ' in ops.last_conv_kernel(), ops.last_conv_kernel()
+    kn = ops.last_conv_kernel()
+    assert ', true, ' in kn or 'conv1x1_stream_bf16' in kn, kn
+    assert ('conv1x1_stream_bf16' in kn) == (k == 1 and ci in (64, 128) and co <= 128 and B * H * W >= 131072), kn
     err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
     # column sums of the epilogue = sums of the stored result
@@ -517,7 +522,7 @@ def _bf16_payload(y):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 128, 3, 1, 9, 9), (3, 256, 512, 3, 1, 19, 19), (2, 128, 256, 3, 2, 20, 12), (5, 512, 256, 1, 1, 7, 7),
-                                  (2, 64, 192, 1, 1, 20, 20)])
+                                  (2, 64, 192, 1, 1, 20, 20), (2, 64, 64, 1, 1, 256, 256), (1, 128, 64, 1, 1, 368, 368)])
 def test_bf16_conv_result_and_batchnorm_sweeps_over_it(dev, bf16_mode, case):
     """conv mode 'bf16': the plane conv may leave its result y as bf16 (y_bf16; half the bytes for the three BatchNorm sweeps
     that read it).  (1) the stored values are the fp32 results rounded to nearest-even bf16, the epilogue's column sums are
@@ -532,7 +537,8 @@ def test_bf16_conv_result_and_batchnorm_sweeps_over_it(dev, bf16_mode, case):
     y32 = ops.conv_fwd_planes_raw(xp, wd, k, s, stats=False)
     yb, part, n = ops.conv_fwd_planes_raw(xp, wd, k, s, y_bf16=True)
     torch.cuda.synchronize()
-    assert 'true, true, false>' in ops.last_conv_kernel(), ops.last_conv_kernel()
+    kn = ops.last_conv_kernel()                       # (large 1x1 layers with K, N <= 128: the streaming kernel, bf16 result form)
+    assert 'true, true, false>' in kn or ('conv1x1_stream_bf16' in kn and kn.endswith('true>')), kn
     got = _bf16_payload(yb)
     assert torch.equal(got, y32.bfloat16().float())                         # RN-even of the very same accumulators
     st = part.view(torch.float32)[:n * 2 * co].view(n, 2, co).double().sum(0).cpu()

@@ -817,6 +817,9 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float* __restri
 // ---- conv mode 2 (bf16): the "planes" of an activation are its bf16 values, dense per pixel in the FIRST HALF of the fp32-sized
 // row (pitch 4 C bytes: same allocation, same addressing as the f16x2 planes; the second half is never touched)
 __device__ __forceinline__ unsigned short pl_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ unsigned pair_swap_u(unsigned v) {             // value of lane ^ 1 (quad_perm [1, 0, 3, 2])
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);
+}
 __global__ __launch_bounds__(256) void planes_split_bf16_kernel(const float* __restrict__ x, long long ld, long long M, int C,
                                                                 unsigned char* __restrict__ planes, long long pitch, int cvalid) {
     const int C4 = C >> 2;
@@ -832,6 +835,198 @@ __global__ __launch_bounds__(256) void planes_split_bf16_kernel(const float* __r
         *reinterpret_cast<us4*>(planes + m * pitch + c * 2) = o;
     }
 }
+// ==================================================================================== bf16 streaming 1x1 (small K, small N)
+// The 1x1 layers with K, N <= 128 on the large maps (stage 1 / 2 in the bf16 mode) are pure byte movers: 128-256 B in and out per
+// pixel for 8-32 k MACs.  The tile kernel above spends a block launch, two barriers and a filter fetch per 128 pixels on them and
+// reaches 40 % of the HBM rate (64 -> 64 @304^2: 1.39 ms forward against 0.55 of bytes).  Here, as in conv1x1_stream_f16x2
+// (conv_f16x2.hip): the whole bf16 filter stays in LDS for the life of a persistent block, every wave streams its own 32 pixel
+// rows from global memory straight into the A layout of v_mfma_f32_32x32x16_bf16 (lane = pixel, 8 consecutive channels = 16
+// contiguous bytes of the pixel's bf16 row: no conversion, no LDS for activations, no barrier in the loop), the next tile's loads
+// fly under this tile's MFMAs and stores, BatchNorm column sums accumulate in registers (one partial row per block).
+// YB: the result leaves as bf16 (column pairs packed through DPP, sums over the rounded values) -- else fp32 (+ skip operand).
+template <int KS, int NT, int NW, bool YB>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv1x1_stream_bf16(const PlaneConvGeom g) {
+    constexpr int NTHR = NW * 64, TROWS = NW * 32;
+    constexpr int K = KS * 16;
+    constexpr int PITCH = K * 2 + 16;                      // LDS row pitch: conflict-free ds_read_b128 for K = 64 / 128
+    constexpr int N32 = NT * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sb[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    {
+        constexpr int CPR = K / 8;                         // 16-B chunks per filter row
+        for (int i = tid; i < N32 * CPR; i += NTHR) {
+            const int row = i / CPR, ch = i - row * CPR;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < g.N) v = *reinterpret_cast<const u32x4*>(g.wt + (size_t)row * (K * 2) + ch * 16);
+            *reinterpret_cast<u32x4*>(smem_sb + row * PITCH + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+    const unsigned pix_bytes = (unsigned)g.Cs * 4u;
+    const int mtiles = g.mtiles;
+    u32x4 ra0[KS], ra1[KS];
+    const unsigned lane_off = (unsigned)(wave * 32 + fr) * pix_bytes + (unsigned)fh * 16u;
+    auto load = [&](u32x4 (&ra)[KS], int tile) {
+        // window re-based at the tile's first row, ending at row M: rows past M read zeros (the 128-channel maps of stage 1
+        // exceed one 32-bit window at bs = 128)
+        const long long row0 = (long long)tile * TROWS;
+        const unsigned long long left = (unsigned long long)(g.M - row0) * pix_bytes;
+        const __amdgpu_buffer_rsrc_t src_rsrc = y4_make_rsrc(g.src + row0 * (long long)pix_bytes,
+                                                            (unsigned)(left < 0xfffffff0ull ? left : 0xfffffff0ull));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) ra[ks] = __builtin_amdgcn_raw_buffer_load_b128(src_rsrc, (int)lane_off, ks * 32, 0);
+    };
+    float cs[NT], css[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { cs[j] = 0.f; css[j] = 0.f; }
+    const unsigned char* b_frag = smem_sb + fr * PITCH + fh * 16;
+    f32x16 acc[NT];
+    auto mma = [&](u32x4 (&ra)[KS]) {
+        // the filter fragments are loop-invariant: up to 8 of them (32 registers) stay in registers across tiles, more are
+        // re-read from LDS per tile (the K = N = 128 form would spill)
+        if constexpr (KS * NT > 8) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 fa = __builtin_bit_cast(bf16x8, ra[ks]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const bf16x8 fb = *reinterpret_cast<const bf16x8*>(b_frag + (j * 32) * PITCH + ks * 32);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+            }
+        }
+    };
+    // Branch-free epilogue: raw buffer stores on a window re-based at the tile's first row whose extent ends at row M (rows past M
+    // fall out of range and are dropped), the lane's row and column in the vector offset, the accumulator register's row
+    // ((e & 3) + 8 (e >> 2)) times the pitch in the scalar offset (dword stores: no wide-store hazard, see pointwise.hip)
+    const unsigned drow = (unsigned)g.ldd * 4u, rrow = (unsigned)g.ldr * 4u;
+    auto epilogue = [&](int tile) {
+        const long long row0 = (long long)tile * TROWS;
+        const unsigned long long left = (unsigned long long)(g.M - row0);
+        const unsigned long long dby = left * drow, rby = left * rrow;
+        const __amdgpu_buffer_rsrc_t drs = y4_make_rsrc(reinterpret_cast<char*>(g.dst) + row0 * (long long)drow,
+                                                        (unsigned)(dby < 0xfffffff0ull ? dby : 0xfffffff0ull));
+        const __amdgpu_buffer_rsrc_t rrs = y4_make_rsrc(g.res ? reinterpret_cast<const char*>(g.res) + row0 * (long long)rrow : nullptr,
+                                                        g.res ? (unsigned)(rby < 0xfffffff0ull ? rby : 0xfffffff0ull) : 0u);
+        const unsigned lrow = (unsigned)(wave * 32 + 4 * fh);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 32 + fr;
+            const bool nok = n < g.N;
+            if constexpr (YB) {
+                // adjacent lanes hold adjacent columns of one row: the even lane packs both and stores one dword at byte 2 n
+                const bool st = nok && !(fr & 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned vo = st ? (lrow + 8u * q) * drow + (unsigned)n * 2u : 0xffffffffu;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned me = (unsigned)pl_bf16_bits(acc[j][q * 4 + r]);
+                        const float vr = __uint_as_float(me << 16);
+                        cs[j] += vr; css[j] += vr * vr;        // rows past M are exact zeros
+                        const unsigned nb = pair_swap_u(me);
+                        __builtin_amdgcn_raw_buffer_store_b32(me | (nb << 16), drs, (int)vo, (int)(r * drow), PL_ST_POL);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned vo = nok ? (lrow + 8u * q) * drow + (unsigned)n * 4u : 0xffffffffu;
+                    const unsigned ro = nok ? (lrow + 8u * q) * rrow + (unsigned)n * 4u : 0xffffffffu;
+                    float rr[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (g.res) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            rr[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (int)ro, (int)(r * rrow), 0));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[j][q * 4 + r];
+                        cs[j] += v; css[j] += v * v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v + rr[r]), drs, (int)vo, (int)(r * drow), PL_ST_POL);
+                    }
+                }
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < mtiles) load(ra0, tile);
+    while (tile < mtiles) {
+        const int t1 = tile + gridDim.x;
+        if (t1 < mtiles) load(ra1, t1);
+        mma(ra0); epilogue(tile);
+        if (t1 >= mtiles) break;
+        const int t2 = t1 + gridDim.x;
+        if (t2 < mtiles) load(ra0, t2);
+        mma(ra1); epilogue(t1);
+        tile = t2;
+    }
+    if (g.stats) {                                         // one partial row per block: [gridDim][2][N]
+        __syncthreads();                                   // every wave is done with the filter
+        float* red = reinterpret_cast<float*>(smem_sb);    // [NW][N32][2]
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float a = cs[j], b = css[j];
+            a += __shfl_xor(a, 32, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (fh == 0) { red[(wave * N32 + j * 32 + fr) * 2] = a; red[(wave * N32 + j * 32 + fr) * 2 + 1] = b; }
+        }
+        __syncthreads();
+        for (int c = tid; c < N32; c += NTHR) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { a += red[(w * N32 + c) * 2]; b += red[(w * N32 + c) * 2 + 1]; }
+            if (c < g.N) {
+                g.stats[((long long)blockIdx.x * 2 + 0) * g.N + c] = a;
+                g.stats[((long long)blockIdx.x * 2 + 1) * g.N + c] = b;
+            }
+        }
+    }
+}
+
+template <int KS, int NT, int NW, bool YB>
+static int launch_stream_bf16(const PlaneConvGeom& g0, hipStream_t st, int* nparts) {
+    PlaneConvGeom g = g0;
+    g.mtiles = (g.M + NW * 32 - 1) / (NW * 32);
+    g.ntiles = 1;
+    size_t smem = (size_t)NT * 32 * (KS * 32 + 16);
+    const size_t red = (size_t)NW * NT * 32 * 2 * sizeof(float);
+    if (smem < red) smem = red;
+    auto kern = conv1x1_stream_bf16<KS, NT, NW, YB>;
+    static Y4DynLds lds_attr;                              // per device, see common.h
+    if (!lds_attr.ensure(reinterpret_cast<const void*>(kern), smem)) return Y4_ERR_LAUNCH;
+    const int resident = NW == 8 ? 256 : 512;              // blocks per CU: 1 (8 waves) or 2
+    const int grid = g.mtiles < resident ? g.mtiles : resident;
+    if (nparts) *nparts = grid;
+    y4::note_kernel("conv1x1_stream_bf16<%d, %d, %d, %s>", KS, NT, NW, YB ? "true" : "false");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), smem, st, g);
+    Y4_CHECK_LAUNCH();
+    return Y4_OK;
+}
+// eligibility: bf16 operands, 1x1 stride 1, K in {64, 128}, N <= 128, rows enough for a persistent launch (Y4_BF_STREAM=0: off)
+static bool stream_bf16_ok(const PlaneConvGeom& g, bool dst_bf16) {
+    static const bool off = getenv("Y4_BF_STREAM") && atoi(getenv("Y4_BF_STREAM")) == 0;
+    if (off || g.k != 1 || g.stride != 1 || (g.Cs != 64 && g.Cs != 128) || g.N > 128 || g.N < 1) return false;
+    if (dst_bf16 && (g.res || (g.N & 1))) return false;
+    return g.M >= 128 * 1024;
+}
+template <bool YB>
+static int dispatch_stream_bf16(const PlaneConvGeom& g, hipStream_t st, int* nparts) {
+    const int nt = (g.N + 31) / 32;
+    if (g.Cs == 64) {
+        if (nt == 1) return launch_stream_bf16<4, 1, 4, YB>(g, st, nparts);
+        if (nt == 2) return launch_stream_bf16<4, 2, 4, YB>(g, st, nparts);
+        return launch_stream_bf16<4, 4, 4, YB>(g, st, nparts);
+    }
+    if (nt == 1) return launch_stream_bf16<8, 1, 4, YB>(g, st, nparts);
+    if (nt == 2) return launch_stream_bf16<8, 2, 4, YB>(g, st, nparts);
+    return launch_stream_bf16<8, 4, 4, YB>(g, st, nparts);
+}
+
 // filter [Cout][kk][Cin] fp32 -> bf16, same order (forward operand), and optionally [Cin][kk (mirrored)][Cout] (dgrad operand)
 __global__ __launch_bounds__(256) void bf16_filter_kernel(const float* __restrict__ w, unsigned short* __restrict__ fwd,
                                                           unsigned short* __restrict__ tr, int Cout, int Cin, int kk, int mirror) {
@@ -967,6 +1162,10 @@ int planes_conv(const void* src, const unsigned* src_amax, const void* wt_planes
         quant = (double)c128 * 1.08 < (double)c256;
     }
     const bool small = small_mode == 2 || (small_mode == 1 && (g.K <= 256 || quant)) || (small_mode == 4 && g.K <= 256);   // 4: short K only
+    if (bf && stream_bf16_ok(g, dst_bf16)) {
+        g.K = Cs;
+        return dst_bf16 ? dispatch_stream_bf16<true>(g, st, nparts) : dispatch_stream_bf16<false>(g, st, nparts);
+    }
     if (bf) {
         // 256 x 256 (wave tile 128 x 64) unless its grid quantises badly on 256 CUs or N fits one 128-column tile
         const char* bt = getenv("Y4_BF_TILE");             // experiments / tests: 1: 256x128 always, 2: 256x256 always
