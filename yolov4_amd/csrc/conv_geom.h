@@ -89,7 +89,7 @@ int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_plan
                     int B, int H, int W, int Cin, int Cout, hipStream_t st, bool bf = false);
 int planes_split(const float* x, long long ld, long long M, int C, const unsigned* amax, void* planes, hipStream_t st, bool bf = false,
                  long long pitch_ch = 0, int c_valid = 0);
-void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn = 128);
+void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn = 128, bool bf = false);
 int planes_wgrad_tn(int Cout, bool bf);
 int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const unsigned* dy_amax, float* dw, void* workspace,
                  size_t workspace_bytes, int B, int H, int W, int Cin, int Cout, int k, hipStream_t st, bool bf = false,

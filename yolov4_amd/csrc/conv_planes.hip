@@ -1105,7 +1105,7 @@ static bool wgrad_window_ok(int B, int H, int W, int Cin, int Cout, int k, int s
     if (M >= (1ll << 31) - 65536) return false;            // (32-bit pixel counters in the kernel, with room for a K-step past M)
     if ((unsigned long long)Cout * k * k * Cin * 4ull >= 0xfffffff0ull) return false;
     int ntn, ntj, splits, sps;
-    planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps, planes_wgrad_tn(Cout, bf));
+    planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps, planes_wgrad_tn(Cout, bf), bf);
     const int pad = (k - 1) / 2;
     const unsigned long long range_px = (unsigned long long)sps * 32ull + 2ull * (unsigned long long)(pad * W + pad) + 64ull;
     const unsigned long long range_x = stride == 1 ? range_px : 4ull * range_px + 8ull * (unsigned long long)W + 64ull;
@@ -1223,7 +1223,11 @@ int planes_dgrad_s2(const void* dy, const unsigned* dy_amax, const void* wt_plan
 }
 
 // split-K plan of the plane wgrad: tiles x splits blocks on 256 CUs (one block per CU), minimising rounds x K-steps per block
-void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn) {
+void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, int* ntj, int* splits, int* sps, int tn, bool bf) {
+    // blocks that run at once: one per CU -- two for the bf16 128-row form (72 KB of LDS, 121 registers: two blocks fit a CU), whose
+    // small tiles are latency-bound per K step (a barrier and a DMA wait per 32 pixels): 64 -> 64 @304^2 1.45 -> see DESIGN section 5
+    static const bool two = !(getenv("Y4_BF_WGRAD_2CU") && atoi(getenv("Y4_BF_WGRAD_2CU")) == 0);
+    const int cap = (bf && tn == 128 && two) ? 512 : 256;
     const long long M = (long long)B * H * W;
     const int J = k * k * Cin;
     *ntn = (Cout + tn - 1) / tn;
@@ -1231,10 +1235,10 @@ void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, 
     const int tiles = *ntn * *ntj;
     const long long steps = (M + 31) / 32;
     long long best = -1; int bs = 1;
-    for (int s = 1; s <= 256; ++s) {
+    for (int s = 1; s <= cap; ++s) {
         const long long per = (steps + s - 1) / s;
         if (s > 1 && per < 12) break;
-        const long long rounds = ((long long)tiles * s + 255) / 256;
+        const long long rounds = ((long long)tiles * s + cap - 1) / cap;
         const long long cost = rounds * (per + 6);         // + prologue / epilogue of a block, in K-steps
         if (best < 0 || cost < best) { best = cost; bs = s; }
     }
@@ -1243,13 +1247,15 @@ void planes_wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, int* ntn, 
     *splits = (int)((steps + per - 1) / per);
 }
 
-// bf16 form: 256-row n tiles (wave tile 128 x 64) when Cout fills them
+// bf16 form: 128-row n tiles, two blocks per CU (the 256-row form, wave tile 128 x 64, on request)
 int planes_wgrad_tn(int Cout, bool bf) {
     if (!bf) return 128;
     const char* bt = getenv("Y4_BF_WGRAD_TILE");           // experiments / tests: 128 / 256 forced
     const int bf_tile = bt ? atoi(bt) : 0;
     if (bf_tile == 128 || (bf_tile == 256 && Cout >= 256)) return bf_tile;
-    return (Cout % 256 == 0) ? 256 : 128;
+    // 128-row tiles everywhere: two of those blocks share a CU (planes_wgrad_plan), which beats one block with the 128 x 64 wave
+    // tile -- 758.4 / 756.5 -> 766.3 / 765.4 img/s at bs = 128 (the 256-row form stays for experiments: Y4_BF_WGRAD_TILE=256)
+    return 128;
 }
 
 template <int TN_, bool BF, int S = 1>
@@ -1283,7 +1289,7 @@ int planes_wgrad(const void* x, const unsigned* x_amax, const void* dy, const un
     if (!wgrad_window_ok(B, H, W, Cin, g.ldy_ch, k, stride, bf)) return Y4_ERR_SHAPE;
     g.M = (int)M; g.J = k * k * Cin;
     const int tn = planes_wgrad_tn(Cout, bf);
-    planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split, tn);
+    planes_wgrad_plan(B, H, W, Cin, Cout, k, &g.ntn, &g.ntj, &g.splits, &g.steps_per_split, tn, bf);
     g.x_total_bytes = (unsigned long long)M * stride * stride * Cin * 4ull;
     g.dy_total_bytes = (unsigned long long)M * g.ldy_ch * 4ull;
     g.x_amax = x_amax; g.dy_amax = dy_amax;
@@ -1455,7 +1461,7 @@ size_t y4_conv2d_wgrad_planes_workspace(int B, int H, int W, int Cin, int Cout, 
     // the larger of the two modes' split counts (the mode may be switched between the size query and the call)
     size_t most = 0;
     for (int bf = 0; bf < 2; ++bf) {
-        y4::planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps, y4::planes_wgrad_tn(Cout, bf != 0));
+        y4::planes_wgrad_plan(B, H, W, Cin, Cout, k, &ntn, &ntj, &splits, &sps, y4::planes_wgrad_tn(Cout, bf != 0), bf != 0);
         const size_t need = splits > 1 ? (size_t)splits * Cout * k * k * Cin * sizeof(float) : 0;
         if (need > most) most = need;
     }
